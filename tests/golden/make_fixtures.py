@@ -1,0 +1,518 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING the reference.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    python tests/golden/make_fixtures.py [--ref /root/reference]
+
+The script imports /root/reference/algorithms/offline/iql.py with inert stub
+modules for the third-party packages that are absent here (d4rl, gym, wandb,
+pyrallis, optbnn -- SURVEY.md section 8c), drives the reference's own functions on
+seeded synthetic inputs and stores ONLY inputs and outputs (.npz).  No reference
+source or bytecode is written anywhere.
+
+Two families are written for the training step:
+  *_bf16.npz  the reference as written (torch.amp.autocast bf16 on CPU)
+  *_fp32.npz  the same run with the autocast context replaced by a no-op
+"""
+import argparse
+import contextlib
+import importlib.util
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------- #
+# stand-ins for the absent gp_reward-priors submodule (call-site contract only,
+# iql.py:953-972, 1326-1336): x @ W + b layers, keys layers.0.W / layers.linear_i.W
+# --------------------------------------------------------------------------- #
+class _RLayer(nn.Module):
+    def __init__(self, i, o):
+        super().__init__()
+        self.W = nn.Parameter(torch.zeros(i, o))
+        self.b = nn.Parameter(torch.zeros(o))
+
+    def forward(self, x):
+        return x @ self.W + self.b
+
+
+class StandInRewardMLP(nn.Module):
+    def __init__(self, input_dim, output_dim, hidden_dims, activation_fn="relu"):
+        super().__init__()
+        dims = [input_dim] + list(hidden_dims)
+        self.layers = nn.ModuleDict()
+        self.layers["0"] = _RLayer(dims[0], dims[1])
+        for i in range(1, len(hidden_dims)):
+            self.layers[f"linear_{i}"] = _RLayer(dims[i], dims[i + 1])
+        self.out = _RLayer(dims[-1], output_dim)
+        self.act = {"relu": torch.relu, "tanh": torch.tanh}[activation_fn]
+
+    def forward(self, x):
+        for k in self.layers:
+            x = self.act(self.layers[k](x))
+        return self.out(x)
+
+    # parameters() order = hidden (W,b)*depth then output (W,b): iql.py:953-961
+
+
+def import_reference(ref_root):
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    stub("d4rl")
+    stub("gym", Env=object)
+    stub("wandb")
+    stub("pyrallis", wrap=lambda *a, **k: (lambda f: f))
+    stub("optbnn")
+    stub("optbnn.bnn")
+    stub("optbnn.bnn.nets")
+    stub("optbnn.bnn.nets.mlp", MLP=StandInRewardMLP)
+    stub("optbnn.bnn.nets.pref_trans", PT=object)
+    path = os.path.join(ref_root, "algorithms", "offline", "iql.py")
+    spec = importlib.util.spec_from_file_location("ref_iql", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.dont_write_bytecode = True
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def params_of(module):
+    return {k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def flat(prefix, d):
+    return {f"{prefix}/{k}": v for k, v in d.items()}
+
+
+def adam_state(opt, module):
+    """exp_avg / exp_avg_sq / step keyed by the module's parameter names."""
+    names = [n for n, _ in module.named_parameters()]
+    out = {}
+    for n, p in zip(names, opt.param_groups[0]["params"]):
+        st = opt.state.get(p, None)
+        if st:
+            out[f"{n}/exp_avg"] = st["exp_avg"].detach().numpy().copy()
+            out[f"{n}/exp_avg_sq"] = st["exp_avg_sq"].detach().numpy().copy()
+            out[f"{n}/step"] = np.asarray(float(st["step"]))
+    return out
+
+
+def synth_dataset(rng, n, s_dim, a_dim, reward="normal"):
+    obs = rng.standard_normal((n, s_dim)).astype(np.float32)
+    nxt = rng.standard_normal((n, s_dim)).astype(np.float32)
+    act = rng.uniform(-1, 1, (n, a_dim)).astype(np.float32)
+    if reward == "normal":
+        rew = rng.standard_normal(n).astype(np.float32)
+    else:  # antmaze-like sparse, then -1 (normalize_reward=1)
+        rew = (rng.uniform(size=n) < 0.05).astype(np.float32) - 1.0
+    term = (rng.uniform(size=n) < 0.02)
+    return {
+        "observations": obs,
+        "actions": act,
+        "rewards": rew,
+        "next_observations": nxt,
+        "terminals": term,
+    }
+
+
+def run_trajectory(ref, *, s_dim, a_dim, hidden, batch, n_rows, k_steps, seed,
+                   beta, iql_tau, discount, tau, deterministic, dropout, max_steps,
+                   fp32, reward_kind):
+    rng = np.random.default_rng(seed)
+    data = synth_dataset(rng, n_rows, s_dim, a_dim, reward_kind)
+    buf = ref.ReplayBuffer(s_dim, a_dim, n_rows + 7, "cpu")
+    buf.load_d4rl_dataset(data)
+
+    torch.manual_seed(seed)
+    q = ref.TwinQ(s_dim, a_dim, hidden_dim=hidden)
+    v = ref.ValueFunction(s_dim, hidden_dim=hidden)
+    pol_cls = ref.DeterministicPolicy if deterministic else ref.GaussianPolicy
+    actor = pol_cls(s_dim, a_dim, 1.0, hidden_dim=hidden, dropout=dropout)
+    if not deterministic:
+        with torch.no_grad():  # non-trivial log_std so its gradient path is exercised
+            actor.log_std.copy_(torch.linspace(-0.5, 0.3, a_dim))
+    vo = torch.optim.Adam(v.parameters(), lr=3e-4)
+    qo = torch.optim.Adam(q.parameters(), lr=3e-4)
+    ao = torch.optim.Adam(actor.parameters(), lr=3e-4)
+    trainer = ref.ImplicitQLearning(
+        max_action=1.0, actor=actor, actor_optimizer=ao, q_network=q, q_optimizer=qo,
+        v_network=v, v_optimizer=vo, iql_tau=iql_tau, beta=beta, max_steps=max_steps,
+        discount=discount, tau=tau, device="cpu")
+
+    out = {}
+    out.update(flat("init/qf", params_of(q)))
+    out.update(flat("init/vf", params_of(v)))
+    out.update(flat("init/actor", params_of(actor)))
+    for k in ("observations", "actions", "rewards", "next_observations"):
+        out[f"data/{k}"] = data[k]
+    out["data/terminals"] = data["terminals"].astype(np.float32)
+
+    # dropout-mask capture: keep/drop decision of the reference's own F.dropout
+    masks = []
+    hooks = []
+    if dropout is not None:
+        def hook(_m, inp, outp):
+            keep = (outp != 0) | (inp[0] == 0)
+            masks.append(keep.detach().numpy().astype(np.uint8))
+        for m in actor.modules():
+            if isinstance(m, nn.Dropout):
+                hooks.append(m.register_forward_hook(hook))
+
+    idx_all = np.zeros((k_steps, batch), dtype=np.int64)
+    losses = np.zeros((k_steps, 3), dtype=np.float64)
+    lrs = np.zeros(k_steps, dtype=np.float64)
+
+    torch.set_autocast_cache_enabled(False)  # SURVEY 8c gotcha: eager + cache fails
+    real_autocast = torch.amp.autocast
+    if fp32:
+        torch.amp.autocast = lambda *a, **k: contextlib.nullcontext()
+    try:
+        g = torch.Generator().manual_seed(seed + 1)
+        for t in range(k_steps):
+            idx = torch.randint(0, n_rows, (batch,), generator=g)
+            idx_all[t] = idx.numpy()
+            b = [buf._states[idx], buf._actions[idx], buf._rewards[idx],
+                 buf._next_states[idx], buf._dones[idx]]
+            lrs[t] = ao.param_groups[0]["lr"]  # lr used BY this step
+            log = trainer.train(b)
+            losses[t] = [log["value_loss"], log["q_loss"], log["actor_loss"]]
+            if t == 0:
+                out.update(flat("step1/qf", params_of(q)))
+                out.update(flat("step1/vf", params_of(v)))
+                out.update(flat("step1/actor", params_of(actor)))
+                out.update(flat("step1/q_target", params_of(trainer.q_target)))
+    finally:
+        torch.amp.autocast = real_autocast
+        for h in hooks:
+            h.remove()
+
+    out["indices"] = idx_all
+    out["losses"] = losses
+    out["actor_lr"] = lrs
+    out["final_actor_lr"] = np.asarray(ao.param_groups[0]["lr"])
+    out.update(flat("final/qf", params_of(q)))
+    out.update(flat("final/vf", params_of(v)))
+    out.update(flat("final/actor", params_of(actor)))
+    out.update(flat("final/q_target", params_of(trainer.q_target)))
+    out.update(flat("final/q_adam", adam_state(qo, q)))
+    out.update(flat("final/v_adam", adam_state(vo, v)))
+    out.update(flat("final/actor_adam", adam_state(ao, actor)))
+    if masks:
+        m = np.stack(masks).reshape(k_steps, 2, batch, hidden)
+        out["dropout_keep"] = np.packbits(m, axis=-1)
+    out["hyper"] = np.asarray(
+        [s_dim, a_dim, hidden, batch, n_rows, k_steps, beta, iql_tau, discount, tau,
+         float(deterministic), -1.0 if dropout is None else dropout, max_steps],
+        dtype=np.float64)
+    sd = trainer.state_dict()
+    out["state_dict_keys"] = np.asarray(sorted(sd.keys()))
+    out["actor_keys"] = np.asarray(list(sd["actor"].keys()))
+    out["qf_keys"] = np.asarray(list(sd["qf"].keys()))
+    out["vf_keys"] = np.asarray(list(sd["vf"].keys()))
+    return out
+
+
+def big_summary(ref, fp32):
+    """H=256, B=256 antmaze shapes: losses + strided parameter samples per mode;
+    the (mode-independent) initial parameters and data go to a shared file."""
+    full = run_trajectory(ref, s_dim=29, a_dim=8, hidden=256, batch=256, n_rows=1024,
+                          k_steps=10, seed=7, beta=10.0, iql_tau=0.9, discount=0.99,
+                          tau=0.005, deterministic=False, dropout=None,
+                          max_steps=1_000_000, fp32=fp32, reward_kind="sparse")
+    keep, common = {}, {}
+    for k, v in full.items():
+        if k.startswith(("init/", "data/")):
+            common[k] = v
+        elif k.startswith(("step1/", "final/")) and v.size > 2048:
+            keep[k + "#stride37"] = v.reshape(-1)[::37].copy()
+            keep[k + "#sum"] = np.asarray(v.astype(np.float64).sum())
+            keep[k + "#abssum"] = np.asarray(np.abs(v.astype(np.float64)).sum())
+        else:
+            keep[k] = v
+    return keep, common
+
+
+def per_op(ref):
+    """G1: single-op vectors in both autocast modes."""
+    out = {}
+    torch.manual_seed(3)
+    rng = np.random.default_rng(3)
+    for (s_dim, a_dim) in ((17, 6), (29, 8), (45, 24)):
+        tag = f"S{s_dim}A{a_dim}"
+        B, H = 32, 64
+        q = ref.TwinQ(s_dim, a_dim, hidden_dim=H)
+        v = ref.ValueFunction(s_dim, hidden_dim=H)
+        g = ref.GaussianPolicy(s_dim, a_dim, 1.0, hidden_dim=H)
+        d = ref.DeterministicPolicy(s_dim, a_dim, 1.0, hidden_dim=H)
+        with torch.no_grad():
+            g.log_std.copy_(torch.linspace(-0.7, 0.4, a_dim))
+        s = torch.from_numpy(rng.standard_normal((B, s_dim)).astype(np.float32))
+        a = torch.from_numpy(rng.uniform(-1, 1, (B, a_dim)).astype(np.float32))
+        out.update(flat(f"{tag}/qf", params_of(q)))
+        out.update(flat(f"{tag}/vf", params_of(v)))
+        out.update(flat(f"{tag}/gauss", params_of(g)))
+        out.update(flat(f"{tag}/det", params_of(d)))
+        out[f"{tag}/s"] = s.numpy()
+        out[f"{tag}/a"] = a.numpy()
+        for mode in ("fp32", "bf16"):
+            ctx = (contextlib.nullcontext() if mode == "fp32"
+                   else torch.amp.autocast("cpu", dtype=torch.bfloat16))
+            with torch.no_grad(), ctx:
+                q1, q2 = q.both(s, a)
+                out[f"{tag}/{mode}/q1"] = q1.float().numpy()
+                out[f"{tag}/{mode}/q2"] = q2.float().numpy()
+                out[f"{tag}/{mode}/qmin"] = q(s, a).float().numpy()
+                out[f"{tag}/{mode}/v"] = v(s).float().numpy()
+                dist = g(s)
+                out[f"{tag}/{mode}/mean"] = dist.mean.float().numpy()
+                out[f"{tag}/{mode}/std"] = dist.stddev.float().numpy()
+                out[f"{tag}/{mode}/logp"] = dist.log_prob(a).sum(-1).float().numpy()
+                out[f"{tag}/{mode}/det"] = d(s).float().numpy()
+    u = torch.from_numpy(rng.standard_normal(257).astype(np.float32))
+    out["asym/u"] = u.numpy()
+    for tau in (0.7, 0.8, 0.9):
+        out[f"asym/tau{tau}"] = np.asarray(ref.asymmetric_l2_loss(u, tau).item())
+        with torch.amp.autocast("cpu", dtype=torch.bfloat16):
+            ub = u.to(torch.bfloat16)
+            out[f"asym/bf16/tau{tau}"] = np.asarray(
+                ref.asymmetric_l2_loss(ub, tau).float().item())
+    # soft_update
+    src, tgt = nn.Linear(5, 3), nn.Linear(5, 3)
+    out["soft/src_w"] = src.weight.detach().numpy().copy()
+    out["soft/tgt_w"] = tgt.weight.detach().numpy().copy()
+    ref.soft_update(tgt, src, 0.005)
+    out["soft/out_w"] = tgt.weight.detach().numpy().copy()
+    return out
+
+
+class _FakeEnv:
+    def __init__(self, max_steps):
+        self._max_episode_steps = max_steps
+
+
+def dataset_ops(ref):
+    """G3/G4/G5: buffer gather, reward post-processing, CVaR, relabel plumbing."""
+    out = {}
+    rng = np.random.default_rng(11)
+
+    # ---- G3 gather + torch CPU randint stream -------------------------------
+    d = synth_dataset(rng, 300, 5, 3)
+    buf = ref.ReplayBuffer(5, 3, 400, "cpu")
+    buf.load_d4rl_dataset(d)
+    torch.manual_seed(123)
+    smp = buf.sample(16)
+    for k, v in zip(("s", "a", "r", "s2", "d"), smp):
+        out[f"g3/sample/{k}"] = v.numpy()
+    for k in d:
+        out[f"g3/data/{k}"] = d[k].astype(np.float32)
+    out["g3/size_pointer"] = np.asarray([buf._size, buf._pointer])
+
+    # ---- G4 reward range / modify_reward / mean-std ------------------------
+    n = 64
+    rew = rng.standard_normal(n).astype(np.float32)
+    term = np.zeros(n, dtype=bool)
+    term[[9, 30, 31, 50]] = True
+    base = {"rewards": rew, "terminals": term}
+    out["g4/rewards"] = rew
+    out["g4/terminals"] = term
+    mn, mx, tl = ref.return_reward_range({"rewards": rew.copy(), "terminals": term}, 12)
+    out["g4/range"] = np.asarray([mn, mx])
+    out["g4/trj_lens"] = tl
+    for nr in range(1, 9):
+        ds = {"rewards": rew.copy(), "terminals": term}
+        ref.modify_reward(ds, "antmaze-medium-diverse-v2", nr, max_episode_steps=12)
+        out[f"g4/antmaze_nr{nr}"] = ds["rewards"]
+    ds = {"rewards": rew.copy(), "terminals": term}
+    ref.modify_reward(ds, "halfcheetah-medium-v2", 1, max_episode_steps=12)
+    out["g4/halfcheetah"] = ds["rewards"]
+    ds = {"rewards": rew.copy(), "terminals": term}
+    ref.modify_reward(ds, "pen-human-v1", 1, max_episode_steps=12)
+    out["g4/pen_untouched"] = ds["rewards"]
+    st = rng.standard_normal((40, 6)).astype(np.float32) * 3 + 1
+    m, s = ref.compute_mean_std(st, 1e-3)
+    out["g4/states"] = st
+    out["g4/mean"], out["g4/std"] = m, s
+    out["g4/normalized"] = ref.normalize_states(st, m, s)
+
+    # ---- CVaR --------------------------------------------------------------
+    preds = rng.standard_normal((10, 33)).astype(np.float32)
+    out["cvar/preds"] = preds
+    for alpha in (0.0, 0.5, 0.9, 0.95):
+        n_tail = max(1, int(np.floor((1.0 - alpha) * preds.shape[0])))
+        kth = min(n_tail, preds.shape[0] - 1)
+        part = np.partition(preds, kth, axis=0)
+        out[f"cvar/vec_alpha{alpha}"] = part[:n_tail].mean(axis=0).astype(np.float32)
+        out[f"cvar/emp_alpha{alpha}"] = np.asarray(
+            [ref.empirical_cvar(preds[:, i], alpha) for i in range(preds.shape[1])])
+        out[f"cvar/stab_alpha{alpha}"] = np.asarray(
+            ref.cvar_stability_check(preds, alpha, n_checks=20))
+    out["cvar/single"] = np.asarray(ref.empirical_cvar(preds[:1, 0], 0.9))
+
+    # ---- G5 relabel plumbing on a 3-episode dataset ------------------------
+    s_dim, a_dim, N = 4, 2, 40
+    ds = {
+        "observations": rng.standard_normal((N, s_dim)).astype(np.float32),
+        "actions": rng.uniform(-1, 1, (N, a_dim)).astype(np.float32),
+        "rewards": np.zeros(N, dtype=np.float32),
+        "terminals": np.zeros(N, dtype=bool),
+        "timeouts": np.zeros(N, dtype=bool),
+    }
+    ds["terminals"][13] = True
+    ds["timeouts"][27] = True
+    for k, v in ds.items():
+        out[f"g5/ds/{k}"] = v.astype(np.float32) if v.dtype == bool else v
+    env = _FakeEnv(15)
+
+    torch.manual_seed(5)
+    rm = StandInRewardMLP(s_dim + a_dim, 1, [8, 8], "relu")
+    with torch.no_grad():
+        for p in rm.parameters():
+            p.copy_(torch.randn_like(p) * 0.5)
+    out.update(flat("g5/rm", params_of(rm)))
+    for use_to in (True, False):
+        dsu = dict(ds)
+        if not use_to:
+            dsu.pop("timeouts")
+        for toe in (False, True):
+            r = ref.qlearning_dataset_mr(env, rm, dataset=dsu, terminate_on_end=toe)
+            tag = f"g5/mr/timeouts{int(use_to)}_toe{int(toe)}"
+            for k, v in r.items():
+                out[f"{tag}/{k}"] = np.asarray(v, dtype=np.float32)
+
+    # PT: record exactly what the reference hands to r_model, chunk by chunk
+    class Recorder(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = nn.Parameter(torch.zeros(1))
+            self.calls = []
+
+        def forward(self, st, ac, ts, am):
+            self.calls.append((st.numpy().copy(), ac.numpy().copy(),
+                               ts.numpy().copy(), am.numpy().copy()))
+            w = torch.arange(1, st.shape[1] + 1, dtype=torch.float32)
+            val = ((st.sum(-1) + 2.0 * ac.sum(-1) + 0.01 * ts.float()) * am * w)
+            val = val.cumsum(1)
+            return {"value": val[:, None, :, None]}, None
+
+    for ql in (5, 20):
+        rec = Recorder()
+        r = ref.qlearning_dataset_pt(env, rec, query_length=ql, dataset=ds)
+        tag = f"g5/pt/ql{ql}"
+        for k, v in r.items():
+            out[f"{tag}/{k}"] = np.asarray(v, dtype=np.float32)
+        out[f"{tag}/win_states"] = np.concatenate([c[0] for c in rec.calls])
+        out[f"{tag}/win_actions"] = np.concatenate([c[1] for c in rec.calls])
+        out[f"{tag}/win_timesteps"] = np.concatenate([c[2] for c in rec.calls])
+        out[f"{tag}/win_mask"] = np.concatenate([c[3] for c in rec.calls])
+
+    # MR snapshot ensemble + BNN: files we write ourselves, read by the reference
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "config.yaml"), "w") as f:
+            f.write("activations: relu\n")
+        snaps = []
+        for ep in range(6):
+            torch.manual_seed(100 + ep)
+            m = StandInRewardMLP(s_dim + a_dim, 1, [8, 8], "relu")
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.copy_(torch.randn_like(p) * 0.5)
+            sd = m.state_dict()
+            if ep % 2:
+                sd = {"_orig_mod." + k: v for k, v in sd.items()}
+            torch.save({"net": sd}, os.path.join(td, f"checkpoint_{ep}.pt"))
+            snaps.append(params_of(m))
+        torch.save({"net": snaps and m.state_dict()}, os.path.join(td, "best_model.pt"))
+        for i, sn in enumerate(snaps):
+            out.update(flat(f"g5/ens/snap{i}", sn))
+        for alpha, burn in ((0.0, 0), (0.5, 1), (0.9, 2)):
+            r = ref.qlearning_dataset_mr_ensemble(env, td, alpha=alpha, burn_in=burn,
+                                                  device="cpu", dataset=ds)
+            tag = f"g5/ens/alpha{alpha}_burn{burn}"
+            for k, v in r.items():
+                out[f"{tag}/{k}"] = np.asarray(v, dtype=np.float32)
+        out["g5/ens/discovered_burn2"] = np.asarray(
+            [os.path.basename(p) for p in ref._discover_mr_snapshots(td, 2)])
+
+        # BNN posterior layout: sampling_f/chain_*/sampled_weights/sampled_weights_0000000
+        all_w = []
+        for c in range(2):
+            cdir = os.path.join(td, "sampling_f", f"chain_{c}", "sampled_weights")
+            os.makedirs(cdir)
+            ws = []
+            for k in range(4):
+                ws.append([rng.standard_normal(sh).astype(np.float32) * 0.5
+                           for sh in ((s_dim + a_dim, 8), (8,), (8, 8), (8,), (8, 1), (1,))])
+            torch.save({"sampled_weights": ws},
+                       os.path.join(cdir, "sampled_weights_0000000"))
+            all_w.extend(ws)
+        for i, w in enumerate(all_w):
+            for j, arr in enumerate(w):
+                out[f"g5/bnn/w{i}/{j}"] = arr
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for alpha, ns in ((0.5, 500), (0.75, 5), (0.0, 0)):
+                r = ref.qlearning_dataset_bnn(env, td, alpha=alpha, n_samples=ns,
+                                              device="cpu", dataset=ds)
+                tag = f"g5/bnn/alpha{alpha}_n{ns}"
+                for k, v in r.items():
+                    out[f"{tag}/{k}"] = np.asarray(v, dtype=np.float32)
+    return out
+
+
+def save(name, d):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **d)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.0f} KiB, {len(d)} arrays")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    args = ap.parse_args()
+    torch.set_num_threads(1)  # fixed summation order for the captured vectors
+    ref = import_reference(args.ref)
+
+    cfgs = {
+        # antmaze hyper-parameters (configs/offline/iql/antmaze/medium_diverse_v2.yaml)
+        "traj_antmaze": dict(s_dim=29, a_dim=8, hidden=64, batch=64, n_rows=1000,
+                             k_steps=10, seed=0, beta=10.0, iql_tau=0.9, discount=0.99,
+                             tau=0.005, deterministic=False, dropout=None,
+                             max_steps=1000, reward_kind="sparse"),
+        # pen: Gaussian policy with actor_dropout=0.1 (configs/offline/iql/pen/human_v1.yaml)
+        "traj_pen_dropout": dict(s_dim=45, a_dim=24, hidden=64, batch=32, n_rows=500,
+                                 k_steps=6, seed=1, beta=3.0, iql_tau=0.8,
+                                 discount=0.99, tau=0.005, deterministic=False,
+                                 dropout=0.1, max_steps=50, reward_kind="normal"),
+        # halfcheetah shapes with the deterministic policy branch (iql.py:626-629)
+        "traj_cheetah_det": dict(s_dim=17, a_dim=6, hidden=64, batch=48, n_rows=700,
+                                 k_steps=6, seed=2, beta=3.0, iql_tau=0.7,
+                                 discount=0.99, tau=0.005, deterministic=True,
+                                 dropout=None, max_steps=100, reward_kind="normal"),
+    }
+    for name, cfg in cfgs.items():
+        for fp32 in (True, False):
+            save(f"{name}_{'fp32' if fp32 else 'bf16'}.npz",
+                 run_trajectory(ref, fp32=fp32, **cfg))
+    for fp32 in (True, False):
+        keep, common = big_summary(ref, fp32)
+        save(f"traj_antmaze_h256_{'fp32' if fp32 else 'bf16'}.npz", keep)
+    save("traj_antmaze_h256_common.npz", common)
+    save("per_op.npz", per_op(ref))
+    save("dataset_ops.npz", dataset_ops(ref))
+
+
+if __name__ == "__main__":
+    main()

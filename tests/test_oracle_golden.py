@@ -1,0 +1,114 @@
+"""The oracle (oracle/) pinned against golden vectors captured from the reference.
+
+CPU only.  tests/golden/*.npz were produced by tests/golden/make_fixtures.py, which
+imports /root/reference/algorithms/offline/iql.py and records inputs/outputs.
+"""
+import numpy as np
+import pytest
+
+from oracle import iql_oracle as orc
+from oracle import philox
+from tests import helpers
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors for philox4x32-10
+    kat = [
+        ((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+        ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2,
+         (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+        ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+         (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)),
+    ]
+    for ctr, key, want in kat:
+        got = philox.philox4x32_10(*[np.asarray([c], dtype=np.uint32) for c in ctr], *key)
+        assert tuple(int(g[0]) for g in got) == want
+
+
+def test_sample_indices_range_and_determinism():
+    a = philox.sample_indices(1234, 7, 256, 1_000_000)
+    b = philox.sample_indices(1234, 7, 256, 1_000_000)
+    c = philox.sample_indices(1234, 8, 256, 1_000_000)
+    assert (a == b).all() and (a != c).any()
+    assert a.min() >= 0 and a.max() < 1_000_000
+    k = philox.dropout_keep(5, 3, 1, 64, 256, 0.1)
+    assert 0.85 < k.mean() < 0.95
+
+
+def test_bf16_rounding_matches_torch():
+    import torch
+    x = np.random.default_rng(0).standard_normal(10000).astype(np.float32) * 37
+    x[:4] = [0.0, -0.0, 1.00390625, 3.3895314e38]
+    want = torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+    assert (orc.bf16(x) == want).all()
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", helpers.TRAJ)
+def test_trajectory_matches_reference(name, mode):
+    d, hyper, data, nets = helpers.load_traj(name, mode)
+    o = helpers.make_oracle(hyper, nets, mode)
+    # the H=256 bf16 run sums 256-long bf16 dot products in a different order
+    # than mkldnn: bf16 re-rounding makes that visible at ~1e-4
+    ltol = 1e-5 if (mode == "fp32" or hyper["hidden"] < 256) else 2e-3
+    for t in range(hyper["k_steps"]):
+        assert abs(o.lr["actor"] - d["actor_lr"][t]) <= 1e-12 * d["actor_lr"][t]
+        out = o.train(orc.gather_batch(data, d["indices"][t]), helpers.keep_masks(d, hyper, t))
+        got = np.array([out["value_loss"], out["q_loss"], out["actor_loss"]])
+        np.testing.assert_allclose(got, d["losses"][t], rtol=ltol)
+    assert abs(o.lr["actor"] - float(d["final_actor_lr"])) <= 1e-12 * o.lr["actor"]
+    ptol = 1e-6 if mode == "fp32" else (1e-5 if hyper["hidden"] < 256 else 1e-4)
+    for net, pd in (("qf", o.qf), ("vf", o.vf), ("actor", o.actor), ("q_target", o.q_target)):
+        for k, v in pd.items():
+            want, got = helpers.golden_param(d, f"final/{net}/{k}", v)
+            assert want is not None
+            np.testing.assert_allclose(got, want.reshape(got.shape), atol=ptol, rtol=0)
+    for which, net in (("q", "q_adam"), ("v", "v_adam"), ("actor", "actor_adam")):
+        for k, m in o.m[which].items():
+            want, got = helpers.golden_param(d, f"final/{net}/{k}/exp_avg", m)
+            if want is None:
+                continue
+            scale = np.abs(want).max() + 1e-30
+            tol = 2e-5 if mode == "fp32" else 3e-2
+            assert np.abs(got - want.reshape(got.shape)).max() / scale < tol
+            want2, got2 = helpers.golden_param(d, f"final/{net}/{k}/exp_avg_sq",
+                                               o.v2[which][k])
+            scale2 = np.abs(want2).max() + 1e-30
+            assert np.abs(got2 - want2.reshape(got2.shape)).max() / scale2 < tol
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_per_op_vectors(mode):
+    d = np.load(helpers.GOLDEN + "/per_op.npz")
+    tol = dict(rtol=2e-6, atol=2e-6) if mode == "fp32" else dict(rtol=1e-2, atol=1e-2)
+    for tag in ("S17A6", "S29A8", "S45A24"):
+        get = lambda net: {k.split("/", 2)[2]: d[k] for k in d.files
+                           if k.startswith(f"{tag}/{net}/")}
+        s, a = d[f"{tag}/s"], d[f"{tag}/a"]
+        q1, q2, _, _ = orc.twinq_both(get("qf"), s, a, mode)
+        np.testing.assert_allclose(q1, d[f"{tag}/{mode}/q1"], **tol)
+        np.testing.assert_allclose(q2, d[f"{tag}/{mode}/q2"], **tol)
+        np.testing.assert_allclose(orc.twinq_forward(get("qf"), s, a, mode),
+                                   d[f"{tag}/{mode}/qmin"], **tol)
+        v, _ = orc.value_forward(get("vf"), s, mode)
+        np.testing.assert_allclose(v, d[f"{tag}/{mode}/v"], **tol)
+        mean, std, _ = orc.policy_forward(get("gauss"), s, mode)
+        np.testing.assert_allclose(mean, d[f"{tag}/{mode}/mean"], **tol)
+        np.testing.assert_allclose(std, d[f"{tag}/{mode}/std"][0], rtol=1e-6)
+        np.testing.assert_allclose(orc.gaussian_log_prob(mean, std, a).sum(-1),
+                                   d[f"{tag}/{mode}/logp"], rtol=1e-2 if mode == "bf16" else 1e-5,
+                                   atol=1e-2 if mode == "bf16" else 1e-5)
+        det, _, _ = orc.policy_forward(get("det"), s, mode)
+        np.testing.assert_allclose(det, d[f"{tag}/{mode}/det"], **tol)
+
+
+def test_asymmetric_l2_and_soft_update():
+    d = np.load(helpers.GOLDEN + "/per_op.npz")
+    u = d["asym/u"]
+    for tau in (0.7, 0.8, 0.9):
+        np.testing.assert_allclose(orc.asymmetric_l2_loss(u, tau), d[f"asym/tau{tau}"], rtol=1e-6)
+        np.testing.assert_allclose(orc.asymmetric_l2_loss(orc.bf16(u), tau, "bf16"),
+                                   d[f"asym/bf16/tau{tau}"], rtol=1e-6)
+    tgt = {"w": d["soft/tgt_w"].copy()}
+    orc.soft_update(tgt, {"w": d["soft/src_w"]}, 0.005)
+    np.testing.assert_allclose(tgt["w"], d["soft/out_w"], rtol=1e-6, atol=1e-8)
