@@ -1,0 +1,196 @@
+/*
+ * iqlhip.h -- C-ABI of libiqlhip.so, the MI355X (gfx950) implementation of the
+ * IQL-with-preference-reward hot path of ml4ai/iqlpref.
+ *
+ * The reference has no FFI: its boundary for this path is the Python module
+ * surface of algorithms/offline/iql.py.  Each entry point
+ * below names the reference lines it replaces ("ref:" = that file).  The Python
+ * package iqlpref_amd mirrors the reference classes on top of these calls via
+ * ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - plain C types only; every pointer documented "device" is a HIP device
+ *     pointer owned by the caller (borrowed for the duration stated);
+ *   - every function returns 0 on success and a negative iqlhip_status on
+ *     failure; iqlhip_last_error() returns a thread-local message;
+ *   - all work is enqueued on the hipStream_t passed as `stream` (void*), nothing
+ *     synchronises the host unless stated;
+ *   - one trainer <-> one stream <-> one host thread (not re-entrant per trainer).
+ */
+#ifndef IQLHIP_H
+#define IQLHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  IQLHIP_OK = 0,
+  IQLHIP_ERR_INVALID = -1,     /* bad argument (Python raises ValueError)        */
+  IQLHIP_ERR_HIP = -2,         /* HIP runtime error (Python raises RuntimeError) */
+  IQLHIP_ERR_UNSUPPORTED = -3, /* shape outside what the kernels are built for   */
+  IQLHIP_ERR_NOMEM = -4
+} iqlhip_status;
+
+const char *iqlhip_last_error(void);
+/* ABI version of this header; bumped on any incompatible change. */
+int iqlhip_abi_version(void);
+
+/* ------------------------------------------------------------------------ */
+/* Replay buffer  (ref:164-226 ReplayBuffer)                                 */
+/*                                                                           */
+/* Storage is ONE row-major fp32 matrix [capacity][row_stride]; row i holds  */
+/* transition i as  [ s(S) | a(A) | r | d | s'(S) | pad ]  so that one       */
+/* sample is one contiguous, 16-byte aligned read instead of five.           */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  const float *rows;  /* device, [n_rows][row_stride]          */
+  int64_t n_rows;     /* min(_size,_pointer) of ref:212         */
+  int32_t row_stride; /* floats, multiple of 4                  */
+  int32_t state_dim;
+  int32_t action_dim;
+} iqlhip_replay_view;
+
+/* Row stride (floats) for the given dims: 2S+A+2 rounded up to a multiple of 4. */
+int32_t iqlhip_replay_row_stride(int32_t state_dim, int32_t action_dim);
+
+/* ref:193-209 load_d4rl_dataset: interleave the five device arrays
+ * obs[n][S], act[n][A], rew[n], next_obs[n][S], done[n] (fp32) into
+ * rows[first_row .. first_row+n).                                           */
+int iqlhip_replay_pack(float *rows, int32_t row_stride, int32_t state_dim,
+                       int32_t action_dim, int64_t first_row, int64_t n,
+                       const float *obs, const float *act, const float *rew,
+                       const float *next_obs, const float *done, void *stream);
+
+/* ref:211-221 sample.  idx == NULL: indices are drawn on device,
+ * idx[b] = philox4x32_10(key=seed, ctr=(b, step, stream 0)).x % n_rows
+ * (oracle/philox.py); otherwise idx is a device int64[batch] that is used as
+ * given (parity runs).  Outputs are dense device fp32 tensors
+ * s[B][S] a[B][A] r[B][1] s2[B][S] d[B][1]; idx_out (optional) receives the
+ * indices used.                                                             */
+int iqlhip_replay_sample(const iqlhip_replay_view *view, int32_t batch,
+                         const int64_t *idx, uint64_t seed, uint64_t step, float *s,
+                         float *a, float *r, float *s2, float *d, int64_t *idx_out,
+                         void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Trainer  (ref:546-688 ImplicitQLearning; nets ref:408-543)                 */
+/* ------------------------------------------------------------------------ */
+#define IQLHIP_PREC_FP32 0 /* autocast disabled: exact fp32 MFMA (16x16x4 f32)    */
+#define IQLHIP_PREC_BF16 1 /* ref:650 autocast: bf16 MFMA, fp32 accumulate        */
+
+typedef struct {
+  int32_t state_dim, action_dim;
+  int32_t hidden_dim;    /* multiple of 64, <= 256; n_hidden is fixed at 2         */
+  int32_t batch_size;    /* multiple of 32                                        */
+  int32_t deterministic; /* 1: DeterministicPolicy (ref:485), 0: Gaussian (ref:452)*/
+  int32_t precision;     /* IQLHIP_PREC_*                                         */
+  float dropout_p;       /* actor dropout (ref:436-437); < 0 = none               */
+  float discount, tau, beta, iql_tau; /* ref:558-562                             */
+  double lr_q, lr_v, lr_actor;        /* Adam lr; lr_actor = cosine base lr       */
+  double adam_beta1, adam_beta2, adam_eps;
+  int64_t cosine_t_max;  /* CosineAnnealingLR T_max = max_steps (ref:571)         */
+  uint64_t seed;         /* Philox key for on-device indices and dropout          */
+} iqlhip_trainer_config;
+
+/* Number of fp32 elements and the element offset of every tensor in the
+ * parameter arena.  Order of the 25 offsets: for net in (q1, q2, v, actor):
+ * W1[H][in] b1[H] W2[H][H] b2[H] W3[out][H] b3[out]; then actor log_std[A]
+ * (offset -1 when deterministic).  Torch [out][in] row-major layouts.
+ * The target arena uses the q1,q2 part of the same layout.                  */
+#define IQLHIP_N_TENSORS 25
+int iqlhip_arena_layout(const iqlhip_trainer_config *cfg, int64_t offsets[IQLHIP_N_TENSORS],
+                        int64_t *n_params, int64_t *n_target);
+
+typedef struct {
+  float *params;  /* device fp32 [n_params]  master weights (torch-owned)       */
+  float *exp_avg; /* device fp32 [n_params]  Adam m                             */
+  float *exp_avg_sq; /* device fp32 [n_params]  Adam v                          */
+  float *target;  /* device fp32 [n_target]  q_target (ref:565)                 */
+  float *grads;   /* optional device fp32 [n_params]; when non-NULL every step
+                     also stores the parameter gradients (tests)               */
+} iqlhip_arenas;
+
+typedef struct iqlhip_trainer iqlhip_trainer;
+
+/* Borrows the arenas for the trainer's lifetime; allocates its own workspace
+ * (compute-precision weight copies, activations) on the current device.      */
+int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_config *cfg,
+                          const iqlhip_arenas *arenas);
+int iqlhip_trainer_destroy(iqlhip_trainer *t);
+
+/* Rebuild the compute-precision weight copies from the fp32 masters (call
+ * after the arenas were written from outside: init, load_state_dict).        */
+int iqlhip_trainer_sync_weights(iqlhip_trainer *t, void *stream);
+
+/* total_it (ref:575,640) = optimiser steps taken = Adam `step` = scheduler
+ * last_epoch.                                                                */
+int iqlhip_trainer_set_step(iqlhip_trainer *t, int64_t total_it);
+int iqlhip_trainer_get_step(iqlhip_trainer *t, int64_t *total_it, double *actor_lr);
+int iqlhip_trainer_set_lr(iqlhip_trainer *t, double lr_q, double lr_v, double lr_actor_base);
+
+/* ref:1533-1536 the hot loop body, n_steps times, without host round trips:
+ *   sample (ref:211-221) -> ImplicitQLearning.train (ref:639-662).
+ * idx: NULL (on-device Philox indices) or device int64[n_steps][batch].
+ * dropout_keep: NULL (on-device Philox masks) or device uint8
+ *   [n_steps][2][batch][hidden] (1 = keep); ignored without actor dropout.
+ * losses_out: NULL or device fp32[n_steps][3] = value_loss, q_loss, actor_loss
+ *   of each step (ref:589,607,633).
+ * graph_unroll: > 0 replays a captured hipGraph of that many steps per launch.*/
+int iqlhip_train_steps(iqlhip_trainer *t, const iqlhip_replay_view *view, int64_t n_steps,
+                       const int64_t *idx, const uint8_t *dropout_keep, float *losses_out,
+                       int32_t graph_unroll, void *stream);
+
+/* ref:639-662 train(batch) on an explicit batch of dense device tensors
+ * (shapes as iqlhip_replay_sample produces them).                           */
+int iqlhip_train_batch(iqlhip_trainer *t, const float *s, const float *a, const float *r,
+                       const float *s2, const float *d, const uint8_t *dropout_keep,
+                       float *losses_out, void *stream);
+
+/* Forward passes on the live weights (ref:452-543), n rows (any n >= 1):
+ *   which = 0: q1,q2 -> out[n][2]   (needs a)
+ *   which = 1: v     -> out[n]
+ *   which = 2: actor mean (tanh)  -> out[n][A]   (eval mode: no dropout)
+ *   which = 3: q_target1, q_target2 -> out[n][2]   (needs a)                */
+int iqlhip_forward(iqlhip_trainer *t, int32_t which, const float *s, const float *a,
+                   int64_t n, float *out, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Stand-alone fp32 MLP forward (exact f32 MFMA)                              */
+/*   - nn.Module.forward() of MLP/TwinQ/ValueFunction/policies outside the   */
+/*     autocast region (ref:408-543; eval_actor ref:306-319);                 */
+/*   - the Markovian reward model forward of the relabel paths               */
+/*     (ref:719-724 MR, ref:986-991 BNN, ref:1176-1178 MR ensemble).          */
+/* ------------------------------------------------------------------------ */
+#define IQLHIP_MLP_MAX_LAYERS 8
+typedef struct {
+  int32_t n_layers;                          /* Linear layers, 1..8                */
+  int32_t dims[IQLHIP_MLP_MAX_LAYERS + 1];   /* in, hidden..., out; each <= 256     */
+  const float *weights[IQLHIP_MLP_MAX_LAYERS]; /* device fp32                      */
+  const float *biases[IQLHIP_MLP_MAX_LAYERS];  /* device fp32 [out]                */
+  int32_t w_in_out;   /* 0: W[out][in] (torch nn.Linear); 1: W[in][out] (x @ W)  */
+  int32_t hidden_act; /* 0 relu, 1 tanh                                          */
+  int32_t out_act;    /* 0 none, 1 tanh                                          */
+} iqlhip_mlp_desc;
+
+/* out[n][out_stride] (first dims[n_layers] columns) = MLP(x[n][x_stride]).  */
+int iqlhip_mlp_forward(const iqlhip_mlp_desc *d, const float *x, int64_t n, int32_t x_stride,
+                       float *out, int32_t out_stride, void *stream);
+
+/* Algorithmic traffic and work of one step for this configuration
+ * (SURVEY.md section 8d): bytes = 4B(2S+A+2) + 32 P_train + 8 P_q.          */
+int iqlhip_step_cost(const iqlhip_trainer_config *cfg, double *bytes, double *flops);
+
+/* HIP-event timing of the kernels of the most recent iqlhip_train_steps call
+ * made with timing enabled (bench.py roofline leg).  enable != 0 brackets
+ * every launch of the dominant kernel with events on `stream`.              */
+int iqlhip_trainer_set_timing(iqlhip_trainer *t, int32_t enable);
+/* avg_ms[3] = mean duration of the forward / backward / update kernels.     */
+int iqlhip_trainer_get_timing(iqlhip_trainer *t, double avg_ms[3], int64_t *n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IQLHIP_H */

@@ -1,0 +1,135 @@
+"""ctypes binding of libiqlhip.so (include/iqlhip.h).
+
+There is no CPU fallback: importing this module without the built library, or
+calling into it without a ROCm device, raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libiqlhip.so")
+
+PREC_FP32 = 0
+PREC_BF16 = 1
+N_TENSORS = 25
+MLP_MAX_LAYERS = 8
+ABI_VERSION = 1
+
+ERR_INVALID = -1
+ERR_HIP = -2
+ERR_UNSUPPORTED = -3
+ERR_NOMEM = -4
+
+
+class ReplayView(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("n_rows", C.c_int64), ("row_stride", C.c_int32),
+                ("state_dim", C.c_int32), ("action_dim", C.c_int32)]
+
+
+class TrainerConfig(C.Structure):
+    _fields_ = [("state_dim", C.c_int32), ("action_dim", C.c_int32),
+                ("hidden_dim", C.c_int32), ("batch_size", C.c_int32),
+                ("deterministic", C.c_int32), ("precision", C.c_int32),
+                ("dropout_p", C.c_float),
+                ("discount", C.c_float), ("tau", C.c_float), ("beta", C.c_float),
+                ("iql_tau", C.c_float),
+                ("lr_q", C.c_double), ("lr_v", C.c_double), ("lr_actor", C.c_double),
+                ("adam_beta1", C.c_double), ("adam_beta2", C.c_double),
+                ("adam_eps", C.c_double),
+                ("cosine_t_max", C.c_int64), ("seed", C.c_uint64)]
+
+
+class Arenas(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("target", C.c_void_p), ("grads", C.c_void_p)]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("dims", C.c_int32 * (MLP_MAX_LAYERS + 1)),
+                ("weights", C.c_void_p * MLP_MAX_LAYERS),
+                ("biases", C.c_void_p * MLP_MAX_LAYERS),
+                ("w_in_out", C.c_int32), ("hidden_act", C.c_int32), ("out_act", C.c_int32)]
+
+
+# every symbol include/iqlhip.h declares: name -> (restype, argtypes)
+P = C.c_void_p
+SYMBOLS = {
+    "iqlhip_last_error": (C.c_char_p, []),
+    "iqlhip_abi_version": (C.c_int, []),
+    "iqlhip_replay_row_stride": (C.c_int32, [C.c_int32, C.c_int32]),
+    "iqlhip_replay_pack": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                     P, P, P, P, P, P]),
+    "iqlhip_replay_sample": (C.c_int, [C.POINTER(ReplayView), C.c_int32, P, C.c_uint64,
+                                       C.c_uint64, P, P, P, P, P, P, P]),
+    "iqlhip_arena_layout": (C.c_int, [C.POINTER(TrainerConfig), C.POINTER(C.c_int64 * N_TENSORS),
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "iqlhip_trainer_create": (C.c_int, [C.POINTER(P), C.POINTER(TrainerConfig), C.POINTER(Arenas)]),
+    "iqlhip_trainer_destroy": (C.c_int, [P]),
+    "iqlhip_trainer_sync_weights": (C.c_int, [P, P]),
+    "iqlhip_trainer_set_step": (C.c_int, [P, C.c_int64]),
+    "iqlhip_trainer_get_step": (C.c_int, [P, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "iqlhip_trainer_set_lr": (C.c_int, [P, C.c_double, C.c_double, C.c_double]),
+    "iqlhip_train_steps": (C.c_int, [P, C.POINTER(ReplayView), C.c_int64, P, P, P, C.c_int32, P]),
+    "iqlhip_train_batch": (C.c_int, [P, P, P, P, P, P, P, P, P]),
+    "iqlhip_forward": (C.c_int, [P, C.c_int32, P, P, C.c_int64, P, P]),
+    "iqlhip_mlp_forward": (C.c_int, [C.POINTER(MlpDesc), P, C.c_int64, C.c_int32, P, C.c_int32, P]),
+    "iqlhip_step_cost": (C.c_int, [C.POINTER(TrainerConfig), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double)]),
+    "iqlhip_trainer_set_timing": (C.c_int, [P, C.c_int32]),
+    "iqlhip_trainer_get_timing": (C.c_int, [P, C.POINTER(C.c_double * 3), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libiqlhip.so; raises ImportError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m iqlpref_amd.build` "
+            "(hipcc --offload-arch=gfx950). iqlpref_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.iqlhip_abi_version() != ABI_VERSION:
+        raise ImportError("libiqlhip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Map a negative iqlhip_status to the exception type the reference raises."""
+    if rc == 0:
+        return
+    msg = load().iqlhip_last_error().decode("utf-8", "replace")
+    if rc == ERR_INVALID:
+        raise ValueError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def require_gpu(device):
+    import torch
+    dev = torch.device(device)
+    if dev.type != "cuda" or not torch.cuda.is_available():
+        raise RuntimeError(
+            f"iqlpref_amd runs on a ROCm GPU only (got device={device!r}, "
+            f"torch.cuda.is_available()={torch.cuda.is_available()}); there is no CPU path")
+    return dev
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

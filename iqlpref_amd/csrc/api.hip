@@ -1,0 +1,565 @@
+// Host side of libiqlhip.so: the extern "C" entry points of include/iqlhip.h,
+// trainer workspace management, hipGraph capture of the step sequence.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/iqlhip.h"
+#include "common.h"
+#include "iql_step.h"
+
+namespace iqlhip {
+size_t fwd_smem_bytes(bool bf16, int H, int k1max);
+size_t bwd_smem_bytes(bool bf16, int H);
+hipError_t launch_forward(bool, const TrainerDesc &, const DevArgs *, const DevCtr *, hipStream_t);
+hipError_t launch_backward(bool, const TrainerDesc &, const DevArgs *, DevCtr *, hipStream_t);
+hipError_t launch_update(bool, const TrainerDesc &, const DevArgs *, DevCtr *, const UpdItem *, int,
+                         hipStream_t);
+hipError_t launch_sync_weights(bool, const TrainerDesc &, hipStream_t);
+hipError_t launch_infer(bool, const TrainerDesc &, const FwdNet &, const float *, const float *, int64_t,
+                        float *, int, hipStream_t);
+
+hipError_t launch_pack(float *rows, int stride, int S, int A, int64_t first, int64_t n, const float *obs,
+                       const float *act, const float *rew, const float *nxt, const float *done,
+                       hipStream_t st);
+hipError_t launch_sample(const iqlhip_replay_view &v, int batch, const int64_t *idx, uint64_t seed,
+                         uint64_t step, float *s, float *a, float *r, float *s2, float *d,
+                         int64_t *idx_out, hipStream_t st);
+hipError_t launch_mlp_f32(const iqlhip_mlp_desc &d, const float *x, int64_t n, int x_stride, float *out,
+                          int out_stride, hipStream_t st);
+}  // namespace iqlhip
+
+using namespace iqlhip;
+
+// ------------------------------------------------------------------ errors --
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(IQLHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                  __LINE__);                                                                  \
+  } while (0)
+
+extern "C" const char *iqlhip_last_error(void) { return g_err; }
+extern "C" int iqlhip_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------ replay --
+extern "C" int32_t iqlhip_replay_row_stride(int32_t S, int32_t A) { return round_up(2 * S + A + 2, 4); }
+
+extern "C" int iqlhip_replay_pack(float *rows, int32_t row_stride, int32_t S, int32_t A, int64_t first_row,
+                                  int64_t n, const float *obs, const float *act, const float *rew,
+                                  const float *next_obs, const float *done, void *stream) {
+  if (!rows || !obs || !act || !rew || !next_obs || !done) return fail(IQLHIP_ERR_INVALID, "null pointer");
+  if (S <= 0 || A <= 0 || n < 0 || first_row < 0 || row_stride < 2 * S + A + 2 || (row_stride & 3))
+    return fail(IQLHIP_ERR_INVALID, "bad replay geometry S=%d A=%d stride=%d", S, A, row_stride);
+  if (n == 0) return 0;
+  HIP_TRY(launch_pack(rows, row_stride, S, A, first_row, n, obs, act, rew, next_obs, done,
+                      (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int iqlhip_replay_sample(const iqlhip_replay_view *view, int32_t batch, const int64_t *idx,
+                                    uint64_t seed, uint64_t step, float *s, float *a, float *r, float *s2,
+                                    float *d, int64_t *idx_out, void *stream) {
+  if (!view || !view->rows || !s || !a || !r || !s2 || !d) return fail(IQLHIP_ERR_INVALID, "null pointer");
+  if (batch <= 0) return fail(IQLHIP_ERR_INVALID, "batch must be positive");
+  if (view->n_rows <= 0) return fail(IQLHIP_ERR_INVALID, "cannot sample from an empty replay buffer");
+  HIP_TRY(launch_sample(*view, batch, idx, seed, step, s, a, r, s2, d, idx_out, (hipStream_t)stream));
+  return 0;
+}
+
+// ----------------------------------------------------------------- trainer --
+struct iqlhip_trainer {
+  iqlhip_trainer_config cfg;
+  iqlhip_arenas arenas;
+  TrainerDesc D;
+  bool bf16;
+  void *ws = nullptr;
+  size_t ws_bytes = 0;
+  DevArgs *dargs = nullptr;
+  DevCtr *dctr = nullptr;
+  UpdItem *ditems = nullptr;
+  int n_items = 0;
+  float *batch_rows = nullptr;  // [B][stride] staging for iqlhip_train_batch
+  int64_t total_it = 0;
+  double lr_q, lr_v, lr_a_base;
+  // hipGraph of `graph_unroll` steps
+  hipGraphExec_t gexec = nullptr;
+  int graph_unroll = 0;
+  // timing
+  bool timing = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  double t_acc[3] = {0, 0, 0};
+  int64_t t_n = 0;
+};
+
+static int check_cfg(const iqlhip_trainer_config *c) {
+  if (!c) return fail(IQLHIP_ERR_INVALID, "null config");
+  if (c->state_dim <= 0 || c->action_dim <= 0) return fail(IQLHIP_ERR_INVALID, "bad dims");
+  if (c->hidden_dim < 64 || c->hidden_dim > 256 || c->hidden_dim % 64)
+    return fail(IQLHIP_ERR_UNSUPPORTED, "hidden_dim %d: must be a multiple of 64 in [64, 256]", c->hidden_dim);
+  if (c->batch_size < 16 || c->batch_size % 16)
+    return fail(IQLHIP_ERR_UNSUPPORTED, "batch_size %d: must be a positive multiple of 16", c->batch_size);
+  if (c->action_dim > 32) return fail(IQLHIP_ERR_UNSUPPORTED, "action_dim %d > 32", c->action_dim);
+  if (c->state_dim + c->action_dim > 512) return fail(IQLHIP_ERR_UNSUPPORTED, "state_dim+action_dim > 512");
+  if (c->precision != IQLHIP_PREC_FP32 && c->precision != IQLHIP_PREC_BF16)
+    return fail(IQLHIP_ERR_INVALID, "precision must be IQLHIP_PREC_FP32 or IQLHIP_PREC_BF16");
+  if (c->dropout_p >= 1.0f) return fail(IQLHIP_ERR_INVALID, "dropout_p must be < 1");
+  if (c->cosine_t_max <= 0) return fail(IQLHIP_ERR_INVALID, "cosine_t_max must be positive");
+  return 0;
+}
+
+struct Layout {
+  int64_t off[IQLHIP_N_TENSORS];
+  int64_t n_params, n_target;
+};
+static void net_dims(const iqlhip_trainer_config &c, int net, int *in, int *out) {
+  *in = (net == NET_Q1 || net == NET_Q2) ? c.state_dim + c.action_dim : c.state_dim;
+  *out = (net == NET_A) ? c.action_dim : 1;
+}
+static Layout make_layout(const iqlhip_trainer_config &c) {
+  Layout L;
+  int64_t o = 0;
+  const int H = c.hidden_dim;
+  for (int n = 0; n < N_TRAIN; ++n) {
+    int in, out;
+    net_dims(c, n, &in, &out);
+    const int64_t sz[6] = {(int64_t)H * in, H, (int64_t)H * H, H, (int64_t)out * H, out};
+    for (int k = 0; k < 6; ++k) {
+      L.off[n * 6 + k] = o;
+      o += sz[k];
+    }
+    if (n == NET_Q2) L.n_target = o;
+  }
+  if (c.deterministic) {
+    L.off[24] = -1;
+  } else {
+    L.off[24] = o;
+    o += c.action_dim;
+  }
+  L.n_params = o;
+  return L;
+}
+
+extern "C" int iqlhip_arena_layout(const iqlhip_trainer_config *cfg, int64_t offsets[IQLHIP_N_TENSORS],
+                                   int64_t *n_params, int64_t *n_target) {
+  if (int e = check_cfg(cfg)) return e;
+  const Layout L = make_layout(*cfg);
+  if (offsets) memcpy(offsets, L.off, sizeof(L.off));
+  if (n_params) *n_params = L.n_params;
+  if (n_target) *n_target = L.n_target;
+  return 0;
+}
+
+extern "C" int iqlhip_step_cost(const iqlhip_trainer_config *cfg, double *bytes, double *flops) {
+  if (int e = check_cfg(cfg)) return e;
+  const Layout L = make_layout(*cfg);
+  const double B = cfg->batch_size, S = cfg->state_dim, A = cfg->action_dim, H = cfg->hidden_dim;
+  // gather + (read p,g,m,v; write g,p,m,v) per trained parameter + target r/w
+  if (bytes) *bytes = 4.0 * B * (2 * S + A + 2) + 32.0 * (double)L.n_params + 8.0 * (double)L.n_target;
+  if (flops) {
+    const double wv = S * H + H * H + H, wq = (S + A) * H + H * H + H, wa = S * H + H * H + H * A;
+    const double fwd = 2 * wv + 4 * wq + wa;                     // V twice, target+online twin Q, actor
+    const double dw = wv + 2 * wq + wa;                          // weight gradients
+    const double dx = (H * H + H) * 3 + (H * H + H * A);         // input gradients of layers 3, 2
+    *flops = 2.0 * B * (fwd + dw + dx);
+  }
+  return 0;
+}
+
+template <typename T>
+static T *carve(char *&p, size_t n) {
+  T *r = reinterpret_cast<T *>(p);
+  p += (n * sizeof(T) + 255) / 256 * 256;
+  return r;
+}
+
+extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_config *cfg,
+                                     const iqlhip_arenas *ar) {
+  if (!out) return fail(IQLHIP_ERR_INVALID, "null out");
+  if (int e = check_cfg(cfg)) return e;
+  if (!ar || !ar->params || !ar->exp_avg || !ar->exp_avg_sq || !ar->target)
+    return fail(IQLHIP_ERR_INVALID, "null arena pointer");
+  iqlhip_trainer *t = new (std::nothrow) iqlhip_trainer();
+  if (!t) return fail(IQLHIP_ERR_NOMEM, "host allocation failed");
+  t->cfg = *cfg;
+  t->arenas = *ar;
+  t->bf16 = cfg->precision == IQLHIP_PREC_BF16;
+  t->lr_q = cfg->lr_q, t->lr_v = cfg->lr_v, t->lr_a_base = cfg->lr_actor;
+  const Layout L = make_layout(*cfg);
+  const int S = cfg->state_dim, A = cfg->action_dim, H = cfg->hidden_dim, B = cfg->batch_size;
+  const int es = t->bf16 ? 2 : 4, KM = t->bf16 ? 32 : 16;
+  TrainerDesc &D = t->D;
+  memset(&D, 0, sizeof(D));
+  D.S = S, D.A = A, D.H = H, D.B = B, D.BP = round_up(B, 32);
+  D.OUTW = round_up(OUT_MEAN + A, 4);
+  D.deterministic = cfg->deterministic;
+  D.has_dropout = cfg->dropout_p > 0.f;
+  D.discount = cfg->discount, D.tau = cfg->tau, D.beta = cfg->beta, D.iql_tau = cfg->iql_tau;
+  if (D.has_dropout) {
+    const float scale = 1.0f / (float)(1.0 - (double)cfg->dropout_p);
+    if (t->bf16) {  // noise.div_(1-p) happens in bf16 under autocast (ATen _dropout_impl)
+      uint32_t u;
+      memcpy(&u, &scale, 4);
+      u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+      memcpy(&D.drop_scale, &u, 4);
+    } else {
+      D.drop_scale = scale;
+    }
+    const double thr = (double)cfg->dropout_p * 4294967296.0;
+    D.drop_thr = thr >= 4294967295.0 ? 0xffffffffu : (uint32_t)thr;
+  }
+  D.beta1 = cfg->adam_beta1, D.beta2 = cfg->adam_beta2, D.eps = cfg->adam_eps;
+  D.t_max = cfg->cosine_t_max;
+  D.seed = cfg->seed;
+  D.params = ar->params, D.exp_avg = ar->exp_avg, D.exp_avg_sq = ar->exp_avg_sq;
+  D.target = ar->target, D.grads = ar->grads;
+  D.off_log_std = L.off[24];
+  D.opmax = round_up(A, 16);
+  D.xrows = round_up(S + A, 64);
+  D.k1max = round_up(S + A, KM);
+
+  // ---- workspace ----
+  size_t total = 0;
+  auto add = [&](size_t bytes) { total += (bytes + 255) / 256 * 256; };
+  int k1pad[N_TRAIN], outpad[N_TRAIN], indim[N_TRAIN], outdim[N_TRAIN];
+  for (int n = 0; n < N_TRAIN; ++n) {
+    net_dims(*cfg, n, &indim[n], &outdim[n]);
+    k1pad[n] = round_up(indim[n], KM);
+    outpad[n] = round_up(outdim[n], 16);
+    const int copies = (n <= NET_Q2) ? 2 : 1;  // + target copies
+    for (int c = 0; c < copies; ++c) {
+      add((size_t)H * k1pad[n] * es);
+      add((size_t)H * H * es);
+      add((size_t)outpad[n] * H * es);
+    }
+    add((size_t)H * H * es);  // w2ct
+  }
+  add((size_t)D.xrows * D.BP * es);
+  add((size_t)B * 2 * 4);
+  add((size_t)B * A * 4);
+  add((size_t)4 * 2 * H * D.BP * es);
+  add((size_t)4 * H * D.BP * es);
+  add((size_t)4 * H * D.BP * es);
+  add((size_t)4 * D.opmax * D.BP * es);
+  add((size_t)B * D.OUTW * 4);
+  add((size_t)4 * (B / 16) * 4);
+  add((size_t)(B / 16) * A * 4);
+  const int stride = iqlhip_replay_row_stride(S, A);
+  add((size_t)B * stride * 4);
+  add(sizeof(DevArgs));
+  add(sizeof(DevCtr));
+  // update work items
+  std::vector<UpdItem> items;
+  for (int n = 0; n < N_TRAIN; ++n) {
+    for (int o0 = 0; o0 < H; o0 += 64)
+      for (int i0 = 0; i0 < round_up(indim[n], 16); i0 += 64) items.push_back({n, 0, o0, i0, 1, 0});
+    for (int o0 = 0; o0 < H; o0 += 64)
+      for (int i0 = 0; i0 < H; i0 += 64) items.push_back({n, 1, o0, i0, 1, 0});
+    for (int o0 = 0; o0 < outpad[n]; o0 += 16) items.push_back({n, 2, o0, 0, 0, 1});
+  }
+  t->n_items = (int)items.size();
+  add(items.size() * sizeof(UpdItem));
+
+  if (hipMalloc(&t->ws, total) != hipSuccess) {
+    delete t;
+    return fail(IQLHIP_ERR_NOMEM, "hipMalloc of %zu workspace bytes failed", total);
+  }
+  t->ws_bytes = total;
+  if (hipMemset(t->ws, 0, total) != hipSuccess) {
+    (void)hipFree(t->ws);
+    delete t;
+    return fail(IQLHIP_ERR_HIP, "hipMemset failed");
+  }
+  char *p = reinterpret_cast<char *>(t->ws);
+  for (int n = 0; n < N_TRAIN; ++n) {
+    TrainNet &N = D.net[n];
+    N.in_dim = indim[n], N.k1pad = k1pad[n], N.out_dim = outdim[n], N.out_pad = outpad[n];
+    N.has_target = n <= NET_Q2;
+    for (int k = 0; k < 3; ++k) {
+      N.off_w[k] = L.off[n * 6 + 2 * k];
+      N.off_b[k] = L.off[n * 6 + 2 * k + 1];
+      N.toff_w[k] = N.has_target ? N.off_w[k] : -1;  // target arena = q1,q2 prefix of the layout
+      N.toff_b[k] = N.has_target ? N.off_b[k] : -1;
+    }
+    N.wc[0] = carve<char>(p, (size_t)H * k1pad[n] * es);
+    N.wc[1] = carve<char>(p, (size_t)H * H * es);
+    N.wc[2] = carve<char>(p, (size_t)outpad[n] * H * es);
+    if (N.has_target) {
+      N.tc[0] = carve<char>(p, (size_t)H * k1pad[n] * es);
+      N.tc[1] = carve<char>(p, (size_t)H * H * es);
+      N.tc[2] = carve<char>(p, (size_t)outpad[n] * H * es);
+    }
+    N.w2ct = carve<char>(p, (size_t)H * H * es);
+  }
+  D.xT = carve<char>(p, (size_t)D.xrows * D.BP * es);
+  D.rd = carve<float>(p, (size_t)B * 2);
+  D.actf = carve<float>(p, (size_t)B * A);
+  D.hT = carve<char>(p, (size_t)4 * 2 * H * D.BP * es);
+  D.dz1T = carve<char>(p, (size_t)4 * H * D.BP * es);
+  D.dz2T = carve<char>(p, (size_t)4 * H * D.BP * es);
+  D.dz3T = carve<char>(p, (size_t)4 * D.opmax * D.BP * es);
+  D.outs = carve<float>(p, (size_t)B * D.OUTW);
+  D.lossp = carve<float>(p, (size_t)4 * (B / 16));
+  D.lsp = carve<float>(p, (size_t)(B / 16) * A);
+  t->batch_rows = carve<float>(p, (size_t)B * stride);
+  t->dargs = carve<DevArgs>(p, 1);
+  t->dctr = carve<DevCtr>(p, 1);
+  t->ditems = carve<UpdItem>(p, items.size());
+  if (hipMemcpy(t->ditems, items.data(), items.size() * sizeof(UpdItem), hipMemcpyHostToDevice) !=
+      hipSuccess) {
+    (void)hipFree(t->ws);
+    delete t;
+    return fail(IQLHIP_ERR_HIP, "hipMemcpy of the work items failed");
+  }
+
+  // ---- forward evaluations ----
+  auto mk = [&](int f, int net, bool target, int in_off, int out_col, int slot) {
+    FwdNet &F = D.fwd[f];
+    const TrainNet &N = D.net[net];
+    F.w1c = target ? N.tc[0] : N.wc[0];
+    F.w2c = target ? N.tc[1] : N.wc[1];
+    F.w3c = target ? N.tc[2] : N.wc[2];
+    const float *base = target ? ar->target : ar->params;
+    F.b1 = base + N.off_b[0], F.b2 = base + N.off_b[1], F.b3 = base + N.off_b[2];
+    F.in_off = in_off, F.in_dim = N.in_dim, F.k1pad = N.k1pad;
+    F.out_dim = N.out_dim, F.out_pad = N.out_pad, F.out_col = out_col;
+    F.train_slot = slot;
+    F.tanh_out = net == NET_A;
+    F.dropout = (net == NET_A) && D.has_dropout;
+    F.stage = f == FWD_Q1;
+  };
+  mk(FWD_Q1, NET_Q1, false, 0, OUT_Q1, NET_Q1);
+  mk(FWD_Q2, NET_Q2, false, 0, OUT_Q2, NET_Q2);
+  mk(FWD_V, NET_V, false, 0, OUT_V, NET_V);
+  mk(FWD_A, NET_A, false, 0, OUT_MEAN, NET_A);
+  mk(FWD_QT1, NET_Q1, true, 0, OUT_QT1, -1);
+  mk(FWD_QT2, NET_Q2, true, 0, OUT_QT2, -1);
+  mk(FWD_NV, NET_V, false, S + A + 2, OUT_NV, -1);
+
+  // dynamic LDS above 64 KiB needs no opt-in on gfx950 for these sizes (< 64 KiB)
+  *out = t;
+  return 0;
+}
+
+extern "C" int iqlhip_trainer_destroy(iqlhip_trainer *t) {
+  if (!t) return 0;
+  if (t->gexec) (void)hipGraphExecDestroy(t->gexec);
+  for (auto &e : t->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (t->ws) (void)hipFree(t->ws);
+  delete t;
+  return 0;
+}
+
+extern "C" int iqlhip_trainer_sync_weights(iqlhip_trainer *t, void *stream) {
+  if (!t) return fail(IQLHIP_ERR_INVALID, "null trainer");
+  HIP_TRY(launch_sync_weights(t->bf16, t->D, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int iqlhip_trainer_set_step(iqlhip_trainer *t, int64_t total_it) {
+  if (!t || total_it < 0) return fail(IQLHIP_ERR_INVALID, "bad argument");
+  t->total_it = total_it;
+  DevCtr c;
+  memset(&c, 0, sizeof(c));
+  c.ctr[0] = total_it, c.ctr[1] = total_it;
+  HIP_TRY(hipMemcpy(t->dctr, &c, sizeof(c), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static double cosine_lr(double base, int64_t t, int64_t t_max) {
+  return base * (1.0 + cos(M_PI * (double)t / (double)t_max)) * 0.5;
+}
+
+extern "C" int iqlhip_trainer_get_step(iqlhip_trainer *t, int64_t *total_it, double *actor_lr) {
+  if (!t) return fail(IQLHIP_ERR_INVALID, "null trainer");
+  if (total_it) *total_it = t->total_it;
+  if (actor_lr) *actor_lr = cosine_lr(t->lr_a_base, t->total_it, t->cfg.cosine_t_max);
+  return 0;
+}
+
+extern "C" int iqlhip_trainer_set_lr(iqlhip_trainer *t, double lr_q, double lr_v, double lr_a_base) {
+  if (!t) return fail(IQLHIP_ERR_INVALID, "null trainer");
+  t->lr_q = lr_q, t->lr_v = lr_v, t->lr_a_base = lr_a_base;
+  return 0;
+}
+
+extern "C" int iqlhip_trainer_set_timing(iqlhip_trainer *t, int32_t enable) {
+  if (!t) return fail(IQLHIP_ERR_INVALID, "null trainer");
+  t->timing = enable != 0;
+  t->t_acc[0] = t->t_acc[1] = t->t_acc[2] = 0;
+  t->t_n = 0;
+  if (t->timing)
+    for (auto &e : t->ev)
+      if (!e) HIP_TRY(hipEventCreate(&e));
+  return 0;
+}
+
+extern "C" int iqlhip_trainer_get_timing(iqlhip_trainer *t, double avg_ms[3], int64_t *n) {
+  if (!t) return fail(IQLHIP_ERR_INVALID, "null trainer");
+  for (int k = 0; k < 3; ++k) avg_ms[k] = t->t_n ? t->t_acc[k] / (double)t->t_n : 0.0;
+  if (n) *n = t->t_n;
+  return 0;
+}
+
+static int enqueue_step(iqlhip_trainer *t, hipStream_t st) {
+  HIP_TRY(launch_forward(t->bf16, t->D, t->dargs, t->dctr, st));
+  HIP_TRY(launch_backward(t->bf16, t->D, t->dargs, t->dctr, st));
+  HIP_TRY(launch_update(t->bf16, t->D, t->dargs, t->dctr, t->ditems, t->n_items, st));
+  return 0;
+}
+
+static int run_steps(iqlhip_trainer *t, const DevArgs &args, int64_t n_steps, int graph_unroll,
+                     hipStream_t st) {
+  HIP_TRY(hipMemcpyAsync(t->dargs, &args, sizeof(DevArgs), hipMemcpyHostToDevice, st));
+  int64_t done = 0;
+  if (t->timing) {
+    // one event pair per kernel: serialises the stream a little; diagnostic mode only
+    for (; done < n_steps; ++done) {
+      HIP_TRY(hipEventRecord(t->ev[0], st));
+      HIP_TRY(launch_forward(t->bf16, t->D, t->dargs, t->dctr, st));
+      HIP_TRY(hipEventRecord(t->ev[1], st));
+      HIP_TRY(launch_backward(t->bf16, t->D, t->dargs, t->dctr, st));
+      HIP_TRY(hipEventRecord(t->ev[2], st));
+      HIP_TRY(launch_update(t->bf16, t->D, t->dargs, t->dctr, t->ditems, t->n_items, st));
+      HIP_TRY(hipEventRecord(t->ev[3], st));
+      HIP_TRY(hipEventSynchronize(t->ev[3]));
+      for (int k = 0; k < 3; ++k) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, t->ev[k], t->ev[k + 1]));
+        t->t_acc[k] += ms;
+      }
+      t->t_n++;
+    }
+    return 0;
+  }
+  if (graph_unroll > 0 && n_steps >= graph_unroll) {
+    if (!t->gexec || t->graph_unroll != graph_unroll) {
+      if (t->gexec) {
+        (void)hipGraphExecDestroy(t->gexec);
+        t->gexec = nullptr;
+      }
+      hipGraph_t g = nullptr;
+      HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      int rc = 0;
+      for (int u = 0; u < graph_unroll && !rc; ++u) rc = enqueue_step(t, st);
+      hipError_t ce = hipStreamEndCapture(st, &g);
+      if (rc) return rc;
+      HIP_TRY(ce);
+      HIP_TRY(hipGraphInstantiate(&t->gexec, g, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(g);
+      t->graph_unroll = graph_unroll;
+    }
+    for (; done + graph_unroll <= n_steps; done += graph_unroll) HIP_TRY(hipGraphLaunch(t->gexec, st));
+  }
+  for (; done < n_steps; ++done)
+    if (int rc = enqueue_step(t, st)) return rc;
+  return 0;
+}
+
+extern "C" int iqlhip_train_steps(iqlhip_trainer *t, const iqlhip_replay_view *view, int64_t n_steps,
+                                  const int64_t *idx, const uint8_t *dropout_keep, float *losses_out,
+                                  int32_t graph_unroll, void *stream) {
+  if (!t || !view || !view->rows) return fail(IQLHIP_ERR_INVALID, "null argument");
+  if (n_steps < 0) return fail(IQLHIP_ERR_INVALID, "n_steps must be >= 0");
+  if (view->state_dim != t->cfg.state_dim || view->action_dim != t->cfg.action_dim)
+    return fail(IQLHIP_ERR_INVALID, "replay dims (%d,%d) do not match the trainer (%d,%d)", view->state_dim,
+                view->action_dim, t->cfg.state_dim, t->cfg.action_dim);
+  if (view->n_rows <= 0) return fail(IQLHIP_ERR_INVALID, "cannot sample from an empty replay buffer");
+  if (view->row_stride < 2 * view->state_dim + view->action_dim + 2)
+    return fail(IQLHIP_ERR_INVALID, "row_stride too small");
+  if (n_steps == 0) return 0;
+  DevArgs a;
+  memset(&a, 0, sizeof(a));
+  a.rows = view->rows, a.n_rows = view->n_rows, a.row_stride = view->row_stride;
+  a.idx_mode = idx ? 1 : 0, a.idx = idx;
+  a.drop_keep = dropout_keep, a.losses_out = losses_out;
+  a.base_step = t->total_it;
+  a.lr_q = t->lr_q, a.lr_v = t->lr_v, a.lr_a_base = t->lr_a_base;
+  if (int rc = run_steps(t, a, n_steps, graph_unroll, (hipStream_t)stream)) return rc;
+  t->total_it += n_steps;
+  return 0;
+}
+
+extern "C" int iqlhip_train_batch(iqlhip_trainer *t, const float *s, const float *a, const float *r,
+                                  const float *s2, const float *d, const uint8_t *dropout_keep,
+                                  float *losses_out, void *stream) {
+  if (!t || !s || !a || !r || !s2 || !d) return fail(IQLHIP_ERR_INVALID, "null argument");
+  const int S = t->cfg.state_dim, A = t->cfg.action_dim, B = t->cfg.batch_size;
+  const int stride = iqlhip_replay_row_stride(S, A);
+  HIP_TRY(launch_pack(t->batch_rows, stride, S, A, 0, B, s, a, r, s2, d, (hipStream_t)stream));
+  DevArgs args;
+  memset(&args, 0, sizeof(args));
+  args.rows = t->batch_rows, args.n_rows = B, args.row_stride = stride;
+  args.idx_mode = 2;
+  args.drop_keep = dropout_keep, args.losses_out = losses_out;
+  args.base_step = t->total_it;
+  args.lr_q = t->lr_q, args.lr_v = t->lr_v, args.lr_a_base = t->lr_a_base;
+  if (int rc = run_steps(t, args, 1, 0, (hipStream_t)stream)) return rc;
+  t->total_it += 1;
+  return 0;
+}
+
+extern "C" int iqlhip_forward(iqlhip_trainer *t, int32_t which, const float *s, const float *a, int64_t n,
+                              float *out, void *stream) {
+  if (!t || !s || !out) return fail(IQLHIP_ERR_INVALID, "null argument");
+  if (n <= 0) return fail(IQLHIP_ERR_INVALID, "n must be positive");
+  if ((which == 0 || which == 3) && !a) return fail(IQLHIP_ERR_INVALID, "Q forward needs actions");
+  hipStream_t st = (hipStream_t)stream;
+  FwdNet N;
+  switch (which) {
+    case 0:  // q1, q2 -> out[n][2]
+      N = t->D.fwd[FWD_Q1], N.out_col = 0, N.train_slot = -1, N.stage = 0;
+      HIP_TRY(launch_infer(t->bf16, t->D, N, s, a, n, out, 2, st));
+      N = t->D.fwd[FWD_Q2], N.out_col = 1, N.train_slot = -1, N.stage = 0;
+      HIP_TRY(launch_infer(t->bf16, t->D, N, s, a, n, out, 2, st));
+      return 0;
+    case 1:
+      N = t->D.fwd[FWD_V], N.out_col = 0, N.train_slot = -1;
+      HIP_TRY(launch_infer(t->bf16, t->D, N, s, a, n, out, 1, st));
+      return 0;
+    case 2:  // eval-mode actor: no dropout (ref:299 actor.eval())
+      N = t->D.fwd[FWD_A], N.out_col = 0, N.train_slot = -1, N.dropout = 0;
+      HIP_TRY(launch_infer(t->bf16, t->D, N, s, a, n, out, t->cfg.action_dim, st));
+      return 0;
+    case 3:  // target twin Q -> out[n][2]
+      N = t->D.fwd[FWD_QT1], N.out_col = 0;
+      HIP_TRY(launch_infer(t->bf16, t->D, N, s, a, n, out, 2, st));
+      N = t->D.fwd[FWD_QT2], N.out_col = 1;
+      HIP_TRY(launch_infer(t->bf16, t->D, N, s, a, n, out, 2, st));
+      return 0;
+    default:
+      return fail(IQLHIP_ERR_INVALID, "which must be 0..3");
+  }
+}
+
+extern "C" int iqlhip_mlp_forward(const iqlhip_mlp_desc *d, const float *x, int64_t n, int32_t x_stride,
+                                  float *out, int32_t out_stride, void *stream) {
+  if (!d || !x || !out) return fail(IQLHIP_ERR_INVALID, "null argument");
+  if (n <= 0) return fail(IQLHIP_ERR_INVALID, "n must be positive");
+  if (d->n_layers < 1 || d->n_layers > IQLHIP_MLP_MAX_LAYERS)
+    return fail(IQLHIP_ERR_INVALID, "n_layers must be in [1, %d]", IQLHIP_MLP_MAX_LAYERS);
+  for (int i = 0; i <= d->n_layers; ++i)
+    if (d->dims[i] <= 0 || d->dims[i] > 256)
+      return fail(IQLHIP_ERR_UNSUPPORTED, "layer width %d outside [1, 256]", d->dims[i]);
+  for (int i = 0; i < d->n_layers; ++i)
+    if (!d->weights[i] || !d->biases[i]) return fail(IQLHIP_ERR_INVALID, "null weight pointer");
+  if (x_stride < d->dims[0] || out_stride < d->dims[d->n_layers])
+    return fail(IQLHIP_ERR_INVALID, "stride smaller than the row width");
+  HIP_TRY(launch_mlp_f32(*d, x, n, x_stride, out, out_stride, (hipStream_t)stream));
+  return 0;
+}

@@ -1,0 +1,92 @@
+// Descriptors shared by the host driver and the step kernels (iql_step.hip).
+#pragma once
+#include <stdint.h>
+
+namespace iqlhip {
+
+// The four trained networks and the seven forward evaluations of one step.
+enum { NET_Q1 = 0, NET_Q2 = 1, NET_V = 2, NET_A = 3, N_TRAIN = 4 };
+enum { FWD_Q1 = 0, FWD_Q2, FWD_V, FWD_A, FWD_QT1, FWD_QT2, FWD_NV, N_FWD };
+
+// columns of the per-row forward outputs  outs[B][OUTW]
+enum { OUT_Q1 = 0, OUT_Q2, OUT_V, OUT_QT1, OUT_QT2, OUT_NV, OUT_MEAN };
+
+struct FwdNet {
+  const void *w1c, *w2c, *w3c;  // compute-precision copies [H][k1pad] [H][H] [out_pad][H]
+  const float *b1, *b2, *b3;    // fp32 biases (masters / target arena)
+  int32_t in_off;               // float offset of the input inside a replay row
+  int32_t in_dim, k1pad;        // layer-1 K, padded to the MFMA macro step
+  int32_t out_dim, out_pad;     // layer-3 N, padded to 16
+  int32_t out_col;              // first column in outs[][]
+  int32_t train_slot;           // 0..3: store hidden activations for backward; -1: no
+  int32_t tanh_out;             // actor
+  int32_t dropout;              // actor with dropout
+  int32_t stage;                // this evaluation also writes the batch staging (q1)
+};
+
+struct TrainNet {
+  // fp32 arenas (element offsets are the same in params / exp_avg / exp_avg_sq / grads)
+  int64_t off_w[3], off_b[3];
+  int64_t toff_w[3], toff_b[3];  // target arena offsets (q nets), -1 otherwise
+  void *wc[3];                   // compute copies written by the update kernel
+  void *w2ct;                    // [H][H] transposed copy of layer 2 (backward)
+  void *tc[3];                   // target compute copies (q nets) or null
+  int32_t in_dim, k1pad, out_dim, out_pad;
+  int32_t has_target;
+};
+
+struct TrainerDesc {
+  int32_t S, A, H, B, BP, OUTW, k1max;  // BP: batch leading dimension (B padded to 32)
+  int32_t deterministic, has_dropout;
+  float discount, tau, beta, iql_tau;
+  float drop_scale;      // 1/(1-p), bf16-rounded in bf16 mode (ATen _dropout_impl)
+  uint32_t drop_thr;     // keep iff philox word >= thr
+  double beta1, beta2, eps;
+  int64_t t_max;
+  uint64_t seed;
+  // arenas
+  float *params, *exp_avg, *exp_avg_sq, *target, *grads;
+  int64_t off_log_std;
+  FwdNet fwd[N_FWD];
+  TrainNet net[N_TRAIN];
+  // workspace (T = compute type)
+  void *xT;       // [xrows][B]   layer-1 input (s|a), feature-major
+  float *rd;      // [B][2]       reward, done
+  float *actf;    // [B][A]       actions (fp32, actor loss)
+  void *hT;       // [4][2][H][B] hidden activations (post ReLU / dropout)
+  void *dz1T;     // [4][H][B]
+  void *dz2T;     // [4][H][B]
+  void *dz3T;     // [4][opmax][B]
+  float *outs;    // [B][OUTW]
+  float *lossp;   // [4][nslab]   per-slab loss partial sums
+  float *lsp;     // [nslab][A]   per-slab d(loss)/d(std) partial sums
+  int32_t opmax, xrows;
+};
+
+// Host-written, read-only for the kernels during a launch sequence.
+struct DevArgs {
+  const float *rows;  // replay view
+  int64_t n_rows;
+  int32_t row_stride;
+  int32_t idx_mode;          // 0 philox, 1 injected, 2 identity (explicit batch)
+  const int64_t *idx;        // [n][B] when idx_mode == 1
+  const uint8_t *drop_keep;  // [n][2][B][H] or null (philox masks)
+  float *losses_out;         // [n][3] or null
+  int64_t base_step;         // total_it of the first step of this call
+  double lr_q, lr_v, lr_a_base;
+};
+
+// Device-written counters / metrics.
+struct DevCtr {
+  int64_t ctr[2];  // [0] steps completed (read by fwd/bwd), [1] 1-based Adam step (update)
+  float last_losses[4];
+  double loss_sum[4];
+};
+
+struct UpdItem {
+  int32_t net, layer;  // layer 0..2
+  int32_t o0, i0;      // origin of the work-group's block
+  int32_t wo, wi;      // wave w handles o0 + 16*w*wo, i0 + 64*w*wi
+};
+
+}  // namespace iqlhip

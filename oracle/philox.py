@@ -62,14 +62,17 @@ def sample_indices(seed, step, batch, n_rows):
 def dropout_keep(seed, step, layer, batch, hidden, p):
     """Keep mask [batch, hidden] of dropout layer ``layer`` (1 or 2) at ``step``.
 
-    One Philox call yields 4 words = 4 consecutive hidden units of one row;
-    unit j is kept iff word >= floor(p * 2**32)  (P(keep) = 1 - p).
+    One Philox call covers 4 consecutive batch rows of one hidden unit (the four
+    accumulator registers a lane holds in the MFMA C/D layout): counter word 0 =
+    (row // 4) * hidden + unit, output word (row % 4).  A unit is kept iff its
+    word >= floor(p * 2**32)  (P(keep) = 1 - p).
     """
-    assert hidden % 4 == 0
+    assert batch % 4 == 0
     thr = np.uint32(min(int(p * 4294967296.0), 0xFFFFFFFF))
-    blocks = np.arange(batch * (hidden // 4), dtype=np.uint32)
+    blocks = np.arange((batch // 4) * hidden, dtype=np.uint32)
     r = philox4x32_10(blocks, np.uint32(step & 0xFFFFFFFF),
                       np.uint32((step >> 32) & 0xFFFFFFFF), np.uint32(layer),
                       seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    words = np.stack(r, axis=-1).reshape(batch, hidden)
+    words = np.stack(r, axis=0).reshape(4, batch // 4, hidden)  # [word][row//4][unit]
+    words = words.transpose(1, 0, 2).reshape(batch, hidden)
     return words >= thr

@@ -1,0 +1,254 @@
+"""GPU parity of the HIP path (through the C-ABI) against the oracle and the
+golden vectors captured from the reference.  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import iql_oracle as orc
+from oracle import philox
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gh():
+    from tests import gpu_helpers
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return gpu_helpers
+
+
+def test_replay_pack_views_and_sample(gh):
+    d, hyper, data, nets = helpers.load_traj("traj_antmaze", "fp32")
+    buf = gh.make_buffer(hyper, data)
+    n = hyper["n_rows"]
+    assert buf._size == n and buf._pointer == n
+    np.testing.assert_array_equal(buf._states.cpu().numpy(), data["observations"])
+    np.testing.assert_array_equal(buf._actions.cpu().numpy(), data["actions"])
+    np.testing.assert_array_equal(buf._rewards.cpu().numpy()[:, 0], data["rewards"])
+    np.testing.assert_array_equal(buf._next_states.cpu().numpy(), data["next_observations"])
+    np.testing.assert_array_equal(buf._dones.cpu().numpy()[:, 0], data["terminals"])
+    idx = torch.from_numpy(d["indices"][0]).to(gh.DEV)
+    got = buf.sample(len(idx), indices=idx)
+    want = orc.gather_batch(data, d["indices"][0])
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        np.testing.assert_array_equal(g.cpu().numpy(), w)  # bit exact gather
+    with pytest.raises(ValueError):
+        buf.load_d4rl_dataset(data)
+    with pytest.raises(NotImplementedError):
+        buf.add_transition()
+    # on-device Philox index stream == oracle/philox.py
+    torch.manual_seed(99)
+    b1 = buf.sample(64)
+    b2 = buf.sample(64)
+    for call, b in enumerate((b1, b2)):
+        ix = philox.sample_indices(99, call, 64, n)
+        np.testing.assert_array_equal(b[0].cpu().numpy(), data["observations"][ix])
+        np.testing.assert_array_equal(b[2].cpu().numpy()[:, 0], data["rewards"][ix])
+
+
+def test_oversize_dataset_rejected(gh):
+    import iqlpref_amd as ia
+    buf = ia.ReplayBuffer(3, 2, 5, gh.DEV)
+    data = {"observations": np.zeros((6, 3), np.float32), "actions": np.zeros((6, 2), np.float32),
+            "rewards": np.zeros(6, np.float32), "next_observations": np.zeros((6, 3), np.float32),
+            "terminals": np.zeros(6, np.float32)}
+    with pytest.raises(ValueError):
+        buf.load_d4rl_dataset(data)
+    with pytest.raises(ValueError):
+        buf.sample(4)  # empty buffer
+
+
+def _drop_tensor(d, hyper, gh):
+    if hyper["dropout"] is None:
+        return None
+    m = np.unpackbits(d["dropout_keep"], axis=-1)[..., :hyper["hidden"]]
+    return torch.from_numpy(np.ascontiguousarray(m)).to(gh.DEV)
+
+
+TOL = {
+    # (loss rtol vs oracle, loss rtol vs reference golden, param atol vs oracle, vs golden)
+    "fp32": dict(lo=2e-5, lg=2e-5, po=2e-6, pg=2e-6),
+    "bf16": dict(lo=5e-3, lg=2e-2, po=2e-3, pg=2e-3),
+}
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", helpers.TRAJ)
+def test_trajectory_parity(gh, name, mode):
+    d, hyper, data, nets = helpers.load_traj(name, mode)
+    K, B = hyper["k_steps"], hyper["batch"]
+    tr = gh.make_trainer(hyper, nets, mode)
+    buf = gh.make_buffer(hyper, data)
+    idx = torch.from_numpy(d["indices"]).to(gh.DEV)
+    losses = tr.train_steps(buf, K, B, indices=idx, dropout_keep=_drop_tensor(d, hyper, gh),
+                            graph_unroll=0).cpu().numpy()
+    o = helpers.make_oracle(hyper, nets, mode)
+    want = np.zeros((K, 3))
+    for t in range(K):
+        out = o.train(orc.gather_batch(data, d["indices"][t]), helpers.keep_masks(d, hyper, t))
+        want[t] = [out["value_loss"], out["q_loss"], out["actor_loss"]]
+    tol = TOL[mode]
+    np.testing.assert_allclose(losses, want, rtol=tol["lo"], err_msg="vs oracle")
+    np.testing.assert_allclose(losses, d["losses"], rtol=tol["lg"], err_msg="vs reference golden")
+    assert tr.total_it == K
+    assert abs(tr.actor_optimizer.param_groups[0]["lr"] - float(d["final_actor_lr"])) < 1e-12
+    for net, mod, opar in (("qf", tr.qf, o.qf), ("vf", tr.vf, o.vf), ("actor", tr.actor, o.actor),
+                           ("q_target", tr.q_target, o.q_target)):
+        got = gh.module_params(mod)
+        assert list(got.keys()) == [k.split("/", 2)[2] for k in d.files
+                                    if k.startswith(f"init/{net}/")] or net == "q_target"
+        for k, v in got.items():
+            np.testing.assert_allclose(v, opar[k], atol=tol["po"], rtol=0, err_msg=f"{net}/{k} vs oracle")
+            wantg, gotg = helpers.golden_param(d, f"final/{net}/{k}", v)
+            assert wantg is not None
+            np.testing.assert_allclose(gotg, wantg.reshape(gotg.shape), atol=tol["pg"], rtol=0,
+                                       err_msg=f"{net}/{k} vs golden")
+    # Adam moments (exp_avg = EMA of the gradients: pins the backward pass)
+    for which, opt, mod in (("q", tr.q_optimizer, tr.qf), ("v", tr.v_optimizer, tr.vf),
+                            ("actor", tr.actor_optimizer, tr.actor)):
+        for (pname, p) in mod.named_parameters():
+            st = opt.state[p]
+            assert float(st["step"]) == K
+            m_want = o.m[which][pname]
+            scale = np.abs(m_want).max() + 1e-30
+            err = np.abs(st["exp_avg"].cpu().numpy() - m_want).max() / scale
+            assert err < (1e-4 if mode == "fp32" else 2e-2), (which, pname, err)
+            v_want = o.v2[which][pname]
+            errv = np.abs(st["exp_avg_sq"].cpu().numpy() - v_want).max() / (np.abs(v_want).max() + 1e-30)
+            assert errv < (1e-4 if mode == "fp32" else 4e-2), (which, pname, errv)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_train_batch_equals_fused_and_graph(gh, mode):
+    """train(batch) (explicit batch), train_steps eager and hipGraph replay agree bit for bit."""
+    d, hyper, data, nets = helpers.load_traj("traj_antmaze", mode)
+    K, B = hyper["k_steps"], hyper["batch"]
+    idx = torch.from_numpy(d["indices"]).to(gh.DEV)
+    buf = gh.make_buffer(hyper, data)
+    tr_a = gh.make_trainer(hyper, nets, mode)
+    la = tr_a.train_steps(buf, K, B, indices=idx, graph_unroll=0).cpu().numpy()
+    tr_g = gh.make_trainer(hyper, nets, mode)
+    lg = tr_g.train_steps(buf, K, B, indices=idx, graph_unroll=4).cpu().numpy()
+    tr_b = gh.make_trainer(hyper, nets, mode)
+    lb = []
+    for t in range(K):
+        out = tr_b.train(buf.sample(B, indices=idx[t]))
+        assert set(out) == {"value_loss", "q_loss", "actor_loss"}
+        lb.append([out["value_loss"], out["q_loss"], out["actor_loss"]])
+    np.testing.assert_array_equal(la, lg)
+    np.testing.assert_array_equal(la, np.asarray(lb, dtype=np.float32))
+    for ma, mb in ((tr_a.qf, tr_g.qf), (tr_a.actor, tr_b.actor), (tr_a.q_target, tr_b.q_target)):
+        for (k, va), (_, vb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+            assert torch.equal(va, vb), k
+
+
+def test_device_philox_indices_match_oracle(gh):
+    d, hyper, data, nets = helpers.load_traj("traj_antmaze", "fp32")
+    K, B = 5, hyper["batch"]
+    tr = gh.make_trainer(hyper, nets, "fp32", seed=4242)
+    buf = gh.make_buffer(hyper, data)
+    losses = tr.train_steps(buf, K, B).cpu().numpy()
+    o = helpers.make_oracle(hyper, nets, "fp32")
+    for t in range(K):
+        ix = philox.sample_indices(4242, t, B, hyper["n_rows"])
+        out = o.train(orc.gather_batch(data, ix))
+        np.testing.assert_allclose(losses[t], [out["value_loss"], out["q_loss"], out["actor_loss"]],
+                                   rtol=2e-5)
+
+
+def test_device_philox_dropout_matches_oracle(gh):
+    d, hyper, data, nets = helpers.load_traj("traj_pen_dropout", "fp32")
+    K, B, H = 4, hyper["batch"], hyper["hidden"]
+    tr = gh.make_trainer(hyper, nets, "fp32", seed=77)
+    buf = gh.make_buffer(hyper, data)
+    idx = torch.from_numpy(d["indices"][:K]).to(gh.DEV)
+    losses = tr.train_steps(buf, K, B, indices=idx).cpu().numpy()
+    o = helpers.make_oracle(hyper, nets, "fp32")
+    for t in range(K):
+        km = [philox.dropout_keep(77, t, 1, B, H, hyper["dropout"]),
+              philox.dropout_keep(77, t, 2, B, H, hyper["dropout"])]
+        out = o.train(orc.gather_batch(data, d["indices"][t]), km)
+        np.testing.assert_allclose(losses[t], [out["value_loss"], out["q_loss"], out["actor_loss"]],
+                                   rtol=2e-5)
+
+
+def test_state_dict_roundtrip_and_keys(gh):
+    d, hyper, data, nets = helpers.load_traj("traj_antmaze", "fp32")
+    K, B = hyper["k_steps"], hyper["batch"]
+    idx = torch.from_numpy(d["indices"]).to(gh.DEV)
+    buf = gh.make_buffer(hyper, data)
+    tr = gh.make_trainer(hyper, nets, "fp32")
+    tr.train_steps(buf, 4, B, indices=idx[:4])
+    sd = tr.state_dict()
+    assert sorted(sd.keys()) == list(d["state_dict_keys"])  # ref:664-674
+    assert list(sd["actor"].keys()) == list(d["actor_keys"])
+    assert list(sd["qf"].keys()) == list(d["qf_keys"])
+    assert list(sd["vf"].keys()) == list(d["vf_keys"])
+    sd = {k: (v if not isinstance(v, dict) else __import__("copy").deepcopy(v)) for k, v in sd.items()}
+    rest = tr.train_steps(buf, K - 4, B, indices=idx[4:]).cpu().numpy()
+    # resume in a fresh trainer from the checkpoint: same continuation except the
+    # target net, which the reference rebuilds from qf on load (ref:679)
+    tr2 = gh.make_trainer(hyper, nets, "fp32")
+    tr2.load_state_dict(sd)
+    assert tr2.total_it == 4
+    for k, v in tr2.q_target.state_dict().items():
+        assert torch.equal(v, tr2.qf.state_dict()[k])
+    rest2 = tr2.train_steps(buf, K - 4, B, indices=idx[4:]).cpu().numpy()
+    # q-loss and actor loss of the first resumed step do not involve the target
+    np.testing.assert_allclose(rest2[0, 1], rest[0, 1], rtol=1e-6)
+    assert tr2.total_it == K
+    assert tr2.actor_lr_schedule.state_dict()["last_epoch"] == K
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_per_op_forward_vectors(gh, mode):
+    """Module forward (fp32, outside autocast) and trainer.forward (inside) vs G1 vectors."""
+    d = np.load(helpers.GOLDEN + "/per_op.npz")
+    for tag, (S, A) in (("S17A6", (17, 6)), ("S29A8", (29, 8)), ("S45A24", (45, 24))):
+        get = lambda net: {k.split("/", 2)[2]: d[k] for k in d.files if k.startswith(f"{tag}/{net}/")}
+        hyper = dict(s_dim=S, a_dim=A, hidden=64, deterministic=False, dropout=None, iql_tau=0.7,
+                     beta=3.0, max_steps=100, discount=0.99, tau=0.005)
+        s = torch.from_numpy(d[f"{tag}/s"]).to(gh.DEV)
+        a = torch.from_numpy(d[f"{tag}/a"]).to(gh.DEV)
+        if mode == "fp32":
+            q, v, actor = gh.make_nets(hyper, (get("qf"), get("vf"), get("gauss")))
+            tol = dict(rtol=1e-5, atol=1e-5)
+            q1, q2 = q.both(s, a)
+            np.testing.assert_allclose(q1.cpu().numpy(), d[f"{tag}/fp32/q1"], **tol)
+            np.testing.assert_allclose(q2.cpu().numpy(), d[f"{tag}/fp32/q2"], **tol)
+            np.testing.assert_allclose(q(s, a).cpu().numpy(), d[f"{tag}/fp32/qmin"], **tol)
+            np.testing.assert_allclose(v(s).cpu().numpy(), d[f"{tag}/fp32/v"], **tol)
+            dist = actor(s)
+            np.testing.assert_allclose(dist.mean.cpu().numpy(), d[f"{tag}/fp32/mean"], **tol)
+            np.testing.assert_allclose(dist.log_prob(a).sum(-1).cpu().numpy(), d[f"{tag}/fp32/logp"],
+                                       rtol=1e-4, atol=1e-4)
+            hd = dict(hyper, deterministic=True)
+            _, _, det = gh.make_nets(hd, (get("qf"), get("vf"), get("det")))
+            np.testing.assert_allclose(det(s).cpu().numpy(), d[f"{tag}/fp32/det"], **tol)
+            act = det.act(d[f"{tag}/s"][0], gh.DEV)
+            np.testing.assert_allclose(act, np.clip(d[f"{tag}/fp32/det"][0], -1, 1), **tol)
+        else:
+            tr = gh.make_trainer(hyper, (get("qf"), get("vf"), get("gauss")), "bf16")
+            tol = dict(rtol=1e-2, atol=1e-2)
+            qq = tr.forward("q", s, a).cpu().numpy()
+            np.testing.assert_allclose(qq[:, 0], d[f"{tag}/bf16/q1"], **tol)
+            np.testing.assert_allclose(qq[:, 1], d[f"{tag}/bf16/q2"], **tol)
+            np.testing.assert_allclose(tr.forward("v", s).cpu().numpy()[:, 0], d[f"{tag}/bf16/v"], **tol)
+            np.testing.assert_allclose(tr.forward("actor", s).cpu().numpy(), d[f"{tag}/bf16/mean"], **tol)
+            qt = tr.forward("q_target", s, a).cpu().numpy()
+            np.testing.assert_allclose(qt.min(1), d[f"{tag}/bf16/qmin"], **tol)
+
+
+def test_errors(gh):
+    import iqlpref_amd as ia
+    d, hyper, data, nets = helpers.load_traj("traj_antmaze", "fp32")
+    tr = gh.make_trainer(hyper, nets, "fp32")
+    buf = gh.make_buffer(hyper, data)
+    b = buf.sample(64)
+    b[1] = b[1][:, :3]
+    with pytest.raises(RuntimeError, match="Actions shape missmatch"):
+        tr.train(b)
+    with pytest.raises(RuntimeError):
+        ia.ReplayBuffer(3, 2, 10, "cpu")  # no CPU path
