@@ -99,6 +99,7 @@ struct iqlhip_trainer {
   // hipGraph of `graph_unroll` steps
   hipGraphExec_t gexec = nullptr;
   int graph_unroll = 0;
+  hipStream_t cap_stream = nullptr;  // capture only (the legacy default stream cannot capture)
   // timing
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -358,6 +359,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
 extern "C" int iqlhip_trainer_destroy(iqlhip_trainer *t) {
   if (!t) return 0;
   if (t->gexec) (void)hipGraphExecDestroy(t->gexec);
+  if (t->cap_stream) (void)hipStreamDestroy(t->cap_stream);
   for (auto &e : t->ev)
     if (e) (void)hipEventDestroy(e);
   if (t->ws) (void)hipFree(t->ws);
@@ -454,10 +456,11 @@ static int run_steps(iqlhip_trainer *t, const DevArgs &args, int64_t n_steps, in
         t->gexec = nullptr;
       }
       hipGraph_t g = nullptr;
-      HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      if (!t->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&t->cap_stream, hipStreamNonBlocking));
+      HIP_TRY(hipStreamBeginCapture(t->cap_stream, hipStreamCaptureModeThreadLocal));
       int rc = 0;
-      for (int u = 0; u < graph_unroll && !rc; ++u) rc = enqueue_step(t, st);
-      hipError_t ce = hipStreamEndCapture(st, &g);
+      for (int u = 0; u < graph_unroll && !rc; ++u) rc = enqueue_step(t, t->cap_stream);
+      hipError_t ce = hipStreamEndCapture(t->cap_stream, &g);
       if (rc) return rc;
       HIP_TRY(ce);
       HIP_TRY(hipGraphInstantiate(&t->gexec, g, nullptr, nullptr, 0));
