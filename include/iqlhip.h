@@ -83,8 +83,8 @@ int iqlhip_replay_sample(const iqlhip_replay_view *view, int32_t batch,
 
 typedef struct {
   int32_t state_dim, action_dim;
-  int32_t hidden_dim;    /* multiple of 64, <= 256; n_hidden is fixed at 2         */
-  int32_t batch_size;    /* multiple of 32                                        */
+  int32_t hidden_dim;    /* 64, 128 or 256; n_hidden is fixed at 2                 */
+  int32_t batch_size;    /* multiple of 16                                        */
   int32_t deterministic; /* 1: DeterministicPolicy (ref:485), 0: Gaussian (ref:452)*/
   int32_t precision;     /* IQLHIP_PREC_*                                         */
   float dropout_p;       /* actor dropout (ref:436-437); < 0 = none               */

@@ -16,13 +16,15 @@
 namespace iqlhip {
 size_t fwd_smem_bytes(bool bf16, int H, int k1max);
 size_t bwd_smem_bytes(bool bf16, int H);
-hipError_t launch_forward(bool, const TrainerDesc &, const DevArgs *, const DevCtr *, hipStream_t);
-hipError_t launch_backward(bool, const TrainerDesc &, const DevArgs *, DevCtr *, hipStream_t);
-hipError_t launch_update(bool, const TrainerDesc &, const DevArgs *, DevCtr *, const UpdItem *, int,
+hipError_t launch_forward(bool, const TrainerDesc &, const TrainerDesc *, const DevArgs *, const DevCtr *,
+                          hipStream_t);
+hipError_t launch_backward(bool, const TrainerDesc &, const TrainerDesc *, const DevArgs *, DevCtr *,
+                           hipStream_t);
+hipError_t launch_update(bool, const TrainerDesc *, const DevArgs *, DevCtr *, const UpdItem *, int,
                          hipStream_t);
-hipError_t launch_sync_weights(bool, const TrainerDesc &, hipStream_t);
-hipError_t launch_infer(bool, const TrainerDesc &, const FwdNet &, const float *, const float *, int64_t,
-                        float *, int, hipStream_t);
+hipError_t launch_sync_weights(bool, const TrainerDesc *, hipStream_t);
+hipError_t launch_infer(bool, const TrainerDesc &, const TrainerDesc *, const FwdNet &, const float *,
+                        const float *, int64_t, float *, int, hipStream_t);
 
 hipError_t launch_pack(float *rows, int stride, int S, int A, int64_t first, int64_t n, const float *obs,
                        const float *act, const float *rew, const float *nxt, const float *done,
@@ -89,6 +91,7 @@ struct iqlhip_trainer {
   bool bf16;
   void *ws = nullptr;
   size_t ws_bytes = 0;
+  TrainerDesc *ddesc = nullptr;  // device copy of D (kernels read it through L2, not the kernarg segment)
   DevArgs *dargs = nullptr;
   DevCtr *dctr = nullptr;
   UpdItem *ditems = nullptr;
@@ -110,12 +113,15 @@ struct iqlhip_trainer {
 static int check_cfg(const iqlhip_trainer_config *c) {
   if (!c) return fail(IQLHIP_ERR_INVALID, "null config");
   if (c->state_dim <= 0 || c->action_dim <= 0) return fail(IQLHIP_ERR_INVALID, "bad dims");
-  if (c->hidden_dim < 64 || c->hidden_dim > 256 || c->hidden_dim % 64)
-    return fail(IQLHIP_ERR_UNSUPPORTED, "hidden_dim %d: must be a multiple of 64 in [64, 256]", c->hidden_dim);
+  if (c->hidden_dim != 64 && c->hidden_dim != 128 && c->hidden_dim != 256)
+    return fail(IQLHIP_ERR_UNSUPPORTED, "hidden_dim %d: kernels are built for 64, 128 and 256", c->hidden_dim);
   if (c->batch_size < 16 || c->batch_size % 16)
     return fail(IQLHIP_ERR_UNSUPPORTED, "batch_size %d: must be a positive multiple of 16", c->batch_size);
   if (c->action_dim > 32) return fail(IQLHIP_ERR_UNSUPPORTED, "action_dim %d > 32", c->action_dim);
-  if (c->state_dim + c->action_dim > 512) return fail(IQLHIP_ERR_UNSUPPORTED, "state_dim+action_dim > 512");
+  if (c->state_dim + c->action_dim > 128) return fail(IQLHIP_ERR_UNSUPPORTED, "state_dim+action_dim > 128");
+  if ((c->batch_size / 16) * (4 + (c->deterministic ? 0 : c->action_dim)) > 1020)
+    return fail(IQLHIP_ERR_UNSUPPORTED, "batch_size %d too large for action_dim %d", c->batch_size,
+                c->action_dim);
   if (c->precision != IQLHIP_PREC_FP32 && c->precision != IQLHIP_PREC_BF16)
     return fail(IQLHIP_ERR_INVALID, "precision must be IQLHIP_PREC_FP32 or IQLHIP_PREC_BF16");
   if (c->dropout_p >= 1.0f) return fail(IQLHIP_ERR_INVALID, "dropout_p must be < 1");
@@ -263,15 +269,38 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   add((size_t)B * stride * 4);
   add(sizeof(DevArgs));
   add(sizeof(DevCtr));
+  add(sizeof(TrainerDesc));
   // update work items
-  std::vector<UpdItem> items;
+  // Work items of the update kernel, laid out XCD-major: block b runs on XCD b & 7
+  // (round-robin dispatch), network n's tiles go to XCDs 2n and 2n+1 so that the
+  // dZ^T / activation panels they share are fetched into those two L2s only.
+  // (pointers are filled in after the workspace has been carved)
+  std::vector<UpdItem> per_xcd[8];
   for (int n = 0; n < N_TRAIN; ++n) {
+    int k = 0;
+    auto put = [&](int layer, int o0, int i0) {
+      UpdItem it;
+      memset(&it, 0, sizeof(it));
+      it.net = n, it.layer = layer, it.o0 = o0, it.i0 = i0;
+      per_xcd[2 * n + (k++ & 1)].push_back(it);
+    };
     for (int o0 = 0; o0 < H; o0 += 64)
-      for (int i0 = 0; i0 < round_up(indim[n], 16); i0 += 64) items.push_back({n, 0, o0, i0, 1, 0});
+      for (int i0 = 0; i0 < H; i0 += 64) put(1, o0, i0);
     for (int o0 = 0; o0 < H; o0 += 64)
-      for (int i0 = 0; i0 < H; i0 += 64) items.push_back({n, 1, o0, i0, 1, 0});
-    for (int o0 = 0; o0 < outpad[n]; o0 += 16) items.push_back({n, 2, o0, 0, 0, 1});
+      for (int i0 = 0; i0 < round_up(indim[n], 16); i0 += 64) put(0, o0, i0);
+    for (int o0 = 0; o0 < outpad[n]; o0 += 64)
+      for (int i0 = 0; i0 < H; i0 += 64) put(2, o0, i0);
   }
+  size_t depth = 0;
+  for (auto &v : per_xcd) depth = v.size() > depth ? v.size() : depth;
+  std::vector<UpdItem> items;
+  for (size_t d = 0; d < depth; ++d)
+    for (int x = 0; x < 8; ++x) {
+      UpdItem pad;
+      memset(&pad, 0, sizeof(pad));
+      pad.net = -1;
+      items.push_back(d < per_xcd[x].size() ? per_xcd[x][d] : pad);
+    }
   t->n_items = (int)items.size();
   add(items.size() * sizeof(UpdItem));
 
@@ -319,7 +348,26 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   t->batch_rows = carve<float>(p, (size_t)B * stride);
   t->dargs = carve<DevArgs>(p, 1);
   t->dctr = carve<DevCtr>(p, 1);
+  t->ddesc = carve<TrainerDesc>(p, 1);
   t->ditems = carve<UpdItem>(p, items.size());
+  for (auto &it : items) {
+    if (it.net < 0) continue;
+    const TrainNet &N = D.net[it.net];
+    const int L = it.layer;
+    it.Odim = (L == 2) ? N.out_dim : H;
+    it.Idim = (L == 0) ? N.in_dim : H;
+    it.Opad = (L == 2) ? N.out_pad : H;
+    it.Kw = (L == 0) ? N.k1pad : H;
+    it.has_target = N.has_target;
+    it.group = it.net == NET_V ? 1 : (it.net == NET_A ? 2 : 0);
+    it.off_w = N.off_w[L], it.off_b = N.off_b[L], it.toff_w = N.toff_w[L], it.toff_b = N.toff_b[L];
+    it.wc = N.wc[L], it.tc = N.has_target ? N.tc[L] : nullptr, it.w2ct = (L == 1) ? N.w2ct : nullptr;
+    const size_t plane = (size_t)H * D.BP * es;
+    it.Xsrc = (L == 0) ? D.xT : reinterpret_cast<char *>(D.hT) + (size_t)(it.net * 2 + (L - 1)) * plane;
+    it.Zsrc = (L == 0)   ? reinterpret_cast<char *>(D.dz1T) + (size_t)it.net * plane
+              : (L == 1) ? reinterpret_cast<char *>(D.dz2T) + (size_t)it.net * plane
+                         : reinterpret_cast<char *>(D.dz3T) + (size_t)it.net * D.opmax * D.BP * es;
+  }
   if (hipMemcpy(t->ditems, items.data(), items.size() * sizeof(UpdItem), hipMemcpyHostToDevice) !=
       hipSuccess) {
     (void)hipFree(t->ws);
@@ -351,7 +399,11 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   mk(FWD_QT2, NET_Q2, true, 0, OUT_QT2, -1);
   mk(FWD_NV, NET_V, false, S + A + 2, OUT_NV, -1);
 
-  // dynamic LDS above 64 KiB needs no opt-in on gfx950 for these sizes (< 64 KiB)
+  if (hipMemcpy(t->ddesc, &t->D, sizeof(TrainerDesc), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(t->ws);
+    delete t;
+    return fail(IQLHIP_ERR_HIP, "hipMemcpy of the descriptor failed");
+  }
   *out = t;
   return 0;
 }
@@ -369,7 +421,7 @@ extern "C" int iqlhip_trainer_destroy(iqlhip_trainer *t) {
 
 extern "C" int iqlhip_trainer_sync_weights(iqlhip_trainer *t, void *stream) {
   if (!t) return fail(IQLHIP_ERR_INVALID, "null trainer");
-  HIP_TRY(launch_sync_weights(t->bf16, t->D, (hipStream_t)stream));
+  HIP_TRY(launch_sync_weights(t->bf16, t->ddesc, (hipStream_t)stream));
   return 0;
 }
 
@@ -419,9 +471,9 @@ extern "C" int iqlhip_trainer_get_timing(iqlhip_trainer *t, double avg_ms[3], in
 }
 
 static int enqueue_step(iqlhip_trainer *t, hipStream_t st) {
-  HIP_TRY(launch_forward(t->bf16, t->D, t->dargs, t->dctr, st));
-  HIP_TRY(launch_backward(t->bf16, t->D, t->dargs, t->dctr, st));
-  HIP_TRY(launch_update(t->bf16, t->D, t->dargs, t->dctr, t->ditems, t->n_items, st));
+  HIP_TRY(launch_forward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, st));
+  HIP_TRY(launch_backward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, st));
+  HIP_TRY(launch_update(t->bf16, t->ddesc, t->dargs, t->dctr, t->ditems, t->n_items, st));
   return 0;
 }
 
@@ -433,11 +485,11 @@ static int run_steps(iqlhip_trainer *t, const DevArgs &args, int64_t n_steps, in
     // one event pair per kernel: serialises the stream a little; diagnostic mode only
     for (; done < n_steps; ++done) {
       HIP_TRY(hipEventRecord(t->ev[0], st));
-      HIP_TRY(launch_forward(t->bf16, t->D, t->dargs, t->dctr, st));
+      HIP_TRY(launch_forward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, st));
       HIP_TRY(hipEventRecord(t->ev[1], st));
-      HIP_TRY(launch_backward(t->bf16, t->D, t->dargs, t->dctr, st));
+      HIP_TRY(launch_backward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, st));
       HIP_TRY(hipEventRecord(t->ev[2], st));
-      HIP_TRY(launch_update(t->bf16, t->D, t->dargs, t->dctr, t->ditems, t->n_items, st));
+      HIP_TRY(launch_update(t->bf16, t->ddesc, t->dargs, t->dctr, t->ditems, t->n_items, st));
       HIP_TRY(hipEventRecord(t->ev[3], st));
       HIP_TRY(hipEventSynchronize(t->ev[3]));
       for (int k = 0; k < 3; ++k) {
@@ -527,23 +579,23 @@ extern "C" int iqlhip_forward(iqlhip_trainer *t, int32_t which, const float *s, 
   switch (which) {
     case 0:  // q1, q2 -> out[n][2]
       N = t->D.fwd[FWD_Q1], N.out_col = 0, N.train_slot = -1, N.stage = 0;
-      HIP_TRY(launch_infer(t->bf16, t->D, N, s, a, n, out, 2, st));
+      HIP_TRY(launch_infer(t->bf16, t->D, t->ddesc, N, s, a, n, out, 2, st));
       N = t->D.fwd[FWD_Q2], N.out_col = 1, N.train_slot = -1, N.stage = 0;
-      HIP_TRY(launch_infer(t->bf16, t->D, N, s, a, n, out, 2, st));
+      HIP_TRY(launch_infer(t->bf16, t->D, t->ddesc, N, s, a, n, out, 2, st));
       return 0;
     case 1:
       N = t->D.fwd[FWD_V], N.out_col = 0, N.train_slot = -1;
-      HIP_TRY(launch_infer(t->bf16, t->D, N, s, a, n, out, 1, st));
+      HIP_TRY(launch_infer(t->bf16, t->D, t->ddesc, N, s, a, n, out, 1, st));
       return 0;
     case 2:  // eval-mode actor: no dropout (ref:299 actor.eval())
       N = t->D.fwd[FWD_A], N.out_col = 0, N.train_slot = -1, N.dropout = 0;
-      HIP_TRY(launch_infer(t->bf16, t->D, N, s, a, n, out, t->cfg.action_dim, st));
+      HIP_TRY(launch_infer(t->bf16, t->D, t->ddesc, N, s, a, n, out, t->cfg.action_dim, st));
       return 0;
     case 3:  // target twin Q -> out[n][2]
       N = t->D.fwd[FWD_QT1], N.out_col = 0;
-      HIP_TRY(launch_infer(t->bf16, t->D, N, s, a, n, out, 2, st));
+      HIP_TRY(launch_infer(t->bf16, t->D, t->ddesc, N, s, a, n, out, 2, st));
       N = t->D.fwd[FWD_QT2], N.out_col = 1;
-      HIP_TRY(launch_infer(t->bf16, t->D, N, s, a, n, out, 2, st));
+      HIP_TRY(launch_infer(t->bf16, t->D, t->ddesc, N, s, a, n, out, 2, st));
       return 0;
     default:
       return fail(IQLHIP_ERR_INVALID, "which must be 0..3");
@@ -564,5 +616,17 @@ extern "C" int iqlhip_mlp_forward(const iqlhip_mlp_desc *d, const float *x, int6
   if (x_stride < d->dims[0] || out_stride < d->dims[d->n_layers])
     return fail(IQLHIP_ERR_INVALID, "stride smaller than the row width");
   HIP_TRY(launch_mlp_f32(*d, x, n, x_stride, out, out_stride, (hipStream_t)stream));
+  return 0;
+}
+
+// Diagnostic: attach a device buffer [3][512][8][2] u64 for IQL_STAMPS builds.
+extern "C" int iqlhip_trainer_set_debug(iqlhip_trainer *t, void *buf) {
+  if (!t) return fail(IQLHIP_ERR_INVALID, "null trainer");
+  t->D.dbg = reinterpret_cast<unsigned long long *>(buf);
+  HIP_TRY(hipMemcpy(t->ddesc, &t->D, sizeof(TrainerDesc), hipMemcpyHostToDevice));
+  if (t->gexec) {
+    (void)hipGraphExecDestroy(t->gexec);
+    t->gexec = nullptr;
+  }
   return 0;
 }

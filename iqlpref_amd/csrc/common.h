@@ -14,17 +14,46 @@ constexpr int WAVE = 64;
 // ---------------------------------------------------------------- bf16 ----
 // Round-to-nearest-even on the f32 bits (torch's c10::BFloat16 rounding); NaN
 // stays NaN.  Returns the 16-bit pattern.
+// gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, RNE, NaN preserving).
 __device__ __forceinline__ uint16_t f2bf(float x) {
-  uint32_t u = __builtin_bit_cast(uint32_t, x);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+  return __builtin_bit_cast(uint16_t, (__bf16)x);
 }
 __device__ __forceinline__ float bf2f(uint16_t h) {
   return __builtin_bit_cast(float, (uint32_t)h << 16);
 }
 // float -> bf16 -> float
 __device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }
+
+// ------------------------------------------------------- global accesses ----
+// Pointers that the kernels read out of descriptor structs in memory are
+// generic ("flat") to the compiler; flat accesses tie LDS and vector-memory
+// counters together.  Every access to device memory goes through these helpers,
+// which cast to the global address space (global_load / global_store).
+#define IQL_AS1 __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ T ldg(const T *p) {
+  return *(const T IQL_AS1 *)p;
+}
+template <class T>
+__device__ __forceinline__ void stg(T *p, T v) {
+  *(T IQL_AS1 *)p = v;
+}
+// (HIP's uint4/float4 are classes whose copy constructors take generic references,
+// which would turn the access back into a flat one: load builtin vectors instead)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 ldg16(const void *p) {
+  return __builtin_bit_cast(uint4, *(const u32x4_t IQL_AS1 *)p);
+}
+__device__ __forceinline__ uint2 ldg8(const void *p) {
+  return __builtin_bit_cast(uint2, *(const u32x2_t IQL_AS1 *)p);
+}
+__device__ __forceinline__ void stg16(void *p, float4 v) {
+  *(u32x4_t IQL_AS1 *)p = __builtin_bit_cast(u32x4_t, v);
+}
+__device__ __forceinline__ void stg8(void *p, uint2 v) {
+  *(u32x2_t IQL_AS1 *)p = __builtin_bit_cast(u32x2_t, v);
+}
 
 // ------------------------------------------------------------ precision ----
 // One "fragment" is 16 bytes per lane for both precisions.
@@ -69,6 +98,22 @@ struct Prec<false> {
 };
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Fragment-major layout of an [F][K] operand matrix (F padded to 16, K to KM).
+// The 16-byte fragment lane l needs for (16-row tile ft, k-step ks) sits at
+// ((ft*nk + ks)*64 + l)*EPV, so one wave-wide fragment load is ONE contiguous
+// 1 KiB read (8 full 128-B lines) instead of 16 half-used lines of a row-major
+// image.  Element (f, k): lane = ((k % KM) / EPV) * 16 + f % 16, slot = k % EPV.
+// Runs of 4 consecutive k (4-aligned) of one row stay contiguous.
+template <class P>
+__host__ __device__ inline size_t fidx(int f, int k, int nk) {
+  return ((((size_t)(f >> 4) * nk + k / P::KM) * 64) + ((k % P::KM) / P::EPV) * 16 + (f & 15)) * P::EPV +
+         (k % P::EPV);
+}
+template <class P>
+__host__ __device__ inline size_t frag_off(int ft, int ks, int nk, int lane) {
+  return (((size_t)ft * nk + ks) * 64 + lane) * P::EPV;
+}
 
 // --------------------------------------------------------------- Philox ----
 // Philox4x32-10; stream definition in oracle/philox.py.

@@ -61,6 +61,7 @@ struct TrainerDesc {
   float *lossp;   // [4][nslab]   per-slab loss partial sums
   float *lsp;     // [nslab][A]   per-slab d(loss)/d(std) partial sums
   int32_t opmax, xrows;
+  unsigned long long *dbg;  // diagnostic stamps (IQL_STAMPS builds), else null
 };
 
 // Host-written, read-only for the kernels during a launch sequence.
@@ -77,16 +78,28 @@ struct DevArgs {
 };
 
 // Device-written counters / metrics.
+struct AdamCoef {
+  float one_m_b1, b2, one_m_b2, neg_step[3], bc2_sqrt, eps;  // neg_step per group q / v / actor
+};
+
 struct DevCtr {
   int64_t ctr[2];  // [0] steps completed (read by fwd/bwd), [1] 1-based Adam step (update)
   float last_losses[4];
   double loss_sum[4];
+  AdamCoef coef;   // written by a spare forward block for the step in flight
 };
 
+// One work-group of k_update: everything it needs, flattened (no second,
+// dependent descriptor load; no runtime-indexed struct arrays -> no scratch).
 struct UpdItem {
-  int32_t net, layer;  // layer 0..2
-  int32_t o0, i0;      // origin of the work-group's block
-  int32_t wo, wi;      // wave w handles o0 + 16*w*wo, i0 + 64*w*wi
+  int32_t net, layer;      // net < 0: padding slot of the XCD-major table
+  int32_t o0, i0;          // tile origin: out-features [o0, +64) x in-features [i0, +64)
+  int32_t Odim, Idim;      // true extents of the weight matrix
+  int32_t Opad, Kw;        // out-features padded to 16; K extent of the compute copy
+  int32_t has_target, group;  // group: 0 q, 1 v, 2 actor (which Adam step size)
+  int64_t off_w, off_b, toff_w, toff_b;
+  void *wc, *tc, *w2ct;    // compute copies to refresh (w2ct: layer 2 only, else null)
+  const void *Xsrc, *Zsrc; // fragment-major layer input and dZ^T of this (net, layer)
 };
 
 }  // namespace iqlhip

@@ -12,6 +12,11 @@
 //               compute-precision weight copies, and the Polyak target update;
 //               the gradient tile never leaves registers.
 //
+// Every kernel is latency-bound (one 16-row slab per work-group, ~100 work-groups
+// on 256 CUs), so each one issues ALL of its global loads (weight fragments,
+// optimizer state, saved activations) before the first dependent instruction
+// and only then walks its dependency chain.
+//
 // Reference: /root/reference/algorithms/offline/iql.py:581-662 (order of
 // operations), :404-405 (expectile), :127-129 (Polyak), torch.optim.Adam
 // (_single_tensor_adam) and CosineAnnealingLR closed form.
@@ -26,28 +31,64 @@
 namespace iqlhip {
 
 constexpr int SLAB = 16;  // batch rows per work-group (one MFMA M tile)
-constexpr int MAXT = 4;   // n-tiles per wave at H = 256
 
-// ------------------------------------------------------------------------
-// acc[jj] += X[16][K] (LDS, row stride xs) * W^T, W = [N][K] global, for the
-// wave's n-tiles jt = wave*tpw + jj.
-// ------------------------------------------------------------------------
-template <bool BF16>
-__device__ __forceinline__ void slab_gemm(const typename Prec<BF16>::T *x, int xs, int K,
-                                          const typename Prec<BF16>::T *W, int tpw, int wave,
-                                          int lane, f32x4 acc[MAXT]) {
+// Diagnostic build only (-DIQL_STAMPS): per work-group wall-clock (100 MHz) and
+// shader-cycle stamps into D.dbg[kernel][block][8][2]; never compiled into the
+// shipped library.
+#ifdef IQL_STAMPS
+#define STAMP(kern, slot)                                                                   \
+  do {                                                                                      \
+    if (D.dbg && threadIdx.x == 0) {                                                        \
+      unsigned long long *d_ = D.dbg + (((size_t)(kern) * 512 + blockIdx.x) * 8 + (slot)) * 2; \
+      d_[0] = wall_clock64();                                                               \
+      d_[1] = clock64();                                                                    \
+    }                                                                                       \
+  } while (0)
+#else
+#define STAMP(kern, slot) \
+  do {                    \
+  } while (0)
+#endif
+
+template <bool BF16, int H>
+struct KCfg {
   using P = Prec<BF16>;
-  const int r = lane & 15, q = lane >> 4;
-  const typename P::T *xrow = x + r * xs + P::EPV * q;
-  const typename P::T *wrow = W + (size_t)(16 * wave * tpw + r) * K + P::EPV * q;
-  for (int kb = 0; kb < K; kb += P::KM) {
-    const uint4 a = *reinterpret_cast<const uint4 *>(xrow + kb);
+  static constexpr int TPW = H / 64;                 // n-tiles (16 columns) per wave
+  static constexpr int NK2 = H / P::KM;              // k-steps of an H-deep GEMM
+  static constexpr int NKC = NK2 < 8 ? NK2 : 8;      // k-steps held in registers at once
+  static constexpr int NCH = NK2 / NKC;              // register chunks per H-deep GEMM
+  static constexpr int NK1 = BF16 ? 4 : 8;           // layer-1 k-steps in registers (k1pad <= 128)
+  static constexpr int NK3 = NK2 >= 4 ? NK2 / 4 : 1; // layer-3 k-steps per wave (K split over waves)
+  static constexpr int HP = H + P::EPV;              // LDS row stride: +16 B breaks bank conflicts
+};
+
+// w[ks][jj] = B fragment (n-tile tile0+jj, k-step ks0+ks) of a fragment-major weight image
+// with nkw k-steps per tile: one contiguous 1 KiB read per wave instruction
+template <class P, int NK, int TPW>
+__device__ __forceinline__ void load_w(uint4 (&w)[NK][TPW], const typename P::T *W, int nkw, int ks0,
+                                       int nk, int tile0, int lane) {
 #pragma unroll
-    for (int jj = 0; jj < MAXT; ++jj) {
-      if (jj < tpw) {
-        const uint4 b = *reinterpret_cast<const uint4 *>(wrow + (size_t)jj * 16 * K + kb);
-        P::mma(a, b, acc[jj]);
-      }
+  for (int ks = 0; ks < NK; ++ks) {
+    if (ks < nk) {
+#pragma unroll
+      for (int jj = 0; jj < TPW; ++jj)
+        w[ks][jj] = ldg16(W + frag_off<P>(tile0 + jj, ks0 + ks, nkw, lane));
+    }
+  }
+}
+
+// acc[jj] += x[16][k0 .. k0 + nk*KM) (LDS, row stride xs) * w
+template <class P, int NK, int TPW>
+__device__ __forceinline__ void mma_w(const typename P::T *x, int xs, int k0, int nk,
+                                      const uint4 (&w)[NK][TPW], f32x4 (&acc)[TPW], int lane) {
+  const int r = lane & 15, q = lane >> 4;
+  const typename P::T *xrow = x + r * xs + k0 + P::EPV * q;
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    if (ks < nk) {
+      const uint4 a = *reinterpret_cast<const uint4 *>(xrow + ks * P::KM);
+#pragma unroll
+      for (int jj = 0; jj < TPW; ++jj) P::mma(a, w[ks][jj], acc[jj]);
     }
   }
 }
@@ -59,22 +100,22 @@ __device__ __forceinline__ void store4T(typename Prec<BF16>::T *dst, const float
     uint2 u;
     u.x = (uint32_t)P::from_f32(v[0]) | ((uint32_t)P::from_f32(v[1]) << 16);
     u.y = (uint32_t)P::from_f32(v[2]) | ((uint32_t)P::from_f32(v[3]) << 16);
-    *reinterpret_cast<uint2 *>(dst) = u;
+    stg8(dst, u);
   } else {
-    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    stg16(dst, make_float4(v[0], v[1], v[2], v[3]));
   }
 }
 
 template <bool BF16>
 __device__ __forceinline__ void load4T(const typename Prec<BF16>::T *src, float v[4]) {
   if constexpr (BF16) {
-    const uint2 u = *reinterpret_cast<const uint2 *>(src);
+    const uint2 u = ldg8(src);
     v[0] = bf2f((uint16_t)(u.x & 0xffff));
     v[1] = bf2f((uint16_t)(u.x >> 16));
     v[2] = bf2f((uint16_t)(u.y & 0xffff));
     v[3] = bf2f((uint16_t)(u.y >> 16));
   } else {
-    const float4 f = *reinterpret_cast<const float4 *>(src);
+    const float4 f = __builtin_bit_cast(float4, ldg16(src));
     v[0] = f.x, v[1] = f.y, v[2] = f.z, v[3] = f.w;
   }
 }
@@ -86,7 +127,7 @@ __device__ __forceinline__ void dropout_keep4(const TrainerDesc &D, const DevArg
     const uint8_t *m = A.drop_keep +
                        (((size_t)(step - A.base_step) * 2 + layer) * D.B + (size_t)rowblk * 4) * D.H + col;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) keep[i] = m[(size_t)i * D.H] != 0;
+    for (int i = 0; i < 4; ++i) keep[i] = ldg(m + (size_t)i * D.H) != 0;
   } else {
     const Philox4 ph = philox4x32_10((uint32_t)(rowblk * D.H + col), (uint32_t)step,
                                      (uint32_t)((uint64_t)step >> 32),
@@ -100,77 +141,128 @@ __device__ __forceinline__ void dropout_keep4(const TrainerDesc &D, const DevArg
 }
 
 // ------------------------------------------------------------------------
-// Three Linear layers for one 16-row slab whose (padded) input is already in
-// LDS at xs.  Used by the training forward kernel and by iqlhip_forward.
+// Three Linear layers for one 16-row slab.  `fill` writes the (zero padded)
+// input rows into LDS; it runs AFTER the weight fragments of all three layers
+// have been requested, so the replay gather overlaps the weight fetch.
 // ------------------------------------------------------------------------
-template <bool BF16>
+template <bool BF16, int H, class Fill>
 __device__ __forceinline__ void mlp_slab(const FwdNet &N, const TrainerDesc &D, const DevArgs *Ap,
-                                         int64_t step, int slab, typename Prec<BF16>::T *xs,
-                                         typename Prec<BF16>::T *h1, typename Prec<BF16>::T *h2,
-                                         float *red, float *out, int out_stride, int64_t row0,
-                                         int64_t n_valid) {
+                                         int64_t step, int slab, char *smem, float *out, int out_stride,
+                                         int64_t row0, int64_t n_valid, Fill fill) {
+  using K = KCfg<BF16, H>;
   using P = Prec<BF16>;
   using T = typename P::T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int H = D.H, HP = H + P::EPV, K1P = D.k1max + P::EPV;
-  const int tpw = H / 64;
-  const int k1 = N.k1pad;
-  // ---- hidden layers ----
-  T *hin = xs;
-  int hin_stride = K1P, K = k1;
-  const T *Wl = reinterpret_cast<const T *>(N.w1c);
-  const float *bl = N.b1;
-  T *hout = h1;
-#pragma unroll 1
-  for (int layer = 0; layer < 2; ++layer) {
-    f32x4 acc[MAXT];
+  constexpr int HP = K::HP, TPW = K::TPW;
+  const int K1P = D.k1max + P::EPV;
+  T *xs = reinterpret_cast<T *>(smem);                      // [16][K1P]
+  T *h1 = xs + SLAB * K1P;                                  // [16][HP]
+  T *h2 = h1 + SLAB * HP;                                   // [16][HP]
+  float *red = reinterpret_cast<float *>(h2 + SLAB * HP);   // [4][2][64][4]
+
+  STAMP(0, 0);
+  // ---- request every weight fragment this wave will need ----
+  const int nk1 = N.k1pad / P::KM;
+  const int nt3 = N.out_pad / 16;  // 1 or 2
+  uint4 w1[K::NK1][TPW], w2[K::NKC][TPW], w3[K::NK3][2];
+  load_w<P, K::NK1, TPW>(w1, reinterpret_cast<const T *>(N.w1c), nk1, 0, nk1, wave * TPW, lane);
+  load_w<P, K::NKC, TPW>(w2, reinterpret_cast<const T *>(N.w2c), K::NK2, 0, K::NKC, wave * TPW, lane);
 #pragma unroll
-    for (int jj = 0; jj < MAXT; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    slab_gemm<BF16>(hin, hin_stride, K, Wl, tpw, wave, lane, acc);
+  for (int i = 0; i < K::NK3; ++i) {
+    const int ks = wave + 4 * i;
 #pragma unroll
-    for (int jj = 0; jj < MAXT; ++jj) {
-      if (jj < tpw) {
-        const int col = 16 * (wave * tpw + jj) + r;
-        const float bias = P::round(bl[col]);
-        float v[4];
+    for (int jt = 0; jt < 2; ++jt)
+      if (ks < K::NK2 && jt < nt3)
+        w3[i][jt] = ldg16(reinterpret_cast<const T *>(N.w3c) + frag_off<P>(jt, ks, K::NK2, lane));
+  }
+  float bias1[TPW], bias2[TPW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = fmaxf(P::round(acc[jj][i] + bias), 0.f);
-        if (N.dropout) {
-          bool keep[4];
-          dropout_keep4(D, *Ap, step, layer, slab * 4 + q, col, keep);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = keep[i] ? P::round(v[i] * D.drop_scale) : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) hout[(4 * q + i) * HP + col] = P::from_f32(v[i]);
-        if (N.train_slot >= 0) {
-          T *dst = reinterpret_cast<T *>(D.hT) +
-                   ((size_t)(N.train_slot * 2 + layer) * H + col) * D.BP + slab * SLAB + 4 * q;
-          store4T<BF16>(dst, v);
-        }
-      }
-    }
-    __syncthreads();
-    hin = hout, hin_stride = HP, K = H;
-    Wl = reinterpret_cast<const T *>(N.w2c);
-    bl = N.b2;
-    hout = h2;
+  for (int jj = 0; jj < TPW; ++jj) {
+    bias1[jj] = ldg(N.b1 + 16 * (wave * TPW + jj) + r);
+    bias2[jj] = ldg(N.b2 + 16 * (wave * TPW + jj) + r);
   }
 
+  STAMP(0, 1);
+  fill(xs, K1P);
+  __syncthreads();
+  STAMP(0, 2);
+
+  // ---- hidden layer 1 ----
+  {
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int jj = 0; jj < TPW; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma_w<P, K::NK1, TPW>(xs, K1P, 0, nk1, w1, acc, lane);
+#pragma unroll
+    for (int jj = 0; jj < TPW; ++jj) {
+      const int col = 16 * (wave * TPW + jj) + r;
+      const float bias = P::round(bias1[jj]);
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(P::round(acc[jj][i] + bias), 0.f);
+      if (N.dropout) {
+        bool keep[4];
+        dropout_keep4(D, *Ap, step, 0, slab * 4 + q, col, keep);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = keep[i] ? P::round(v[i] * D.drop_scale) : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) h1[(4 * q + i) * HP + col] = P::from_f32(v[i]);
+      if (N.train_slot >= 0)
+        store4T<BF16>(reinterpret_cast<T *>(D.hT) + (size_t)(N.train_slot * 2 + 0) * H * D.BP +
+                          fidx<P>(col, slab * SLAB + 4 * q, D.BP / P::KM), v);
+    }
+  }
+  __syncthreads();
+  STAMP(0, 3);
+
+  // ---- hidden layer 2 ----
+  {
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int jj = 0; jj < TPW; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma_w<P, K::NKC, TPW>(h1, HP, 0, K::NKC, w2, acc, lane);
+#pragma unroll 1
+    for (int ch = 1; ch < K::NCH; ++ch) {
+      load_w<P, K::NKC, TPW>(w2, reinterpret_cast<const T *>(N.w2c), K::NK2, ch * K::NKC, K::NKC,
+                             wave * TPW, lane);
+      mma_w<P, K::NKC, TPW>(h1, HP, ch * K::NKC * P::KM, K::NKC, w2, acc, lane);
+    }
+#pragma unroll
+    for (int jj = 0; jj < TPW; ++jj) {
+      const int col = 16 * (wave * TPW + jj) + r;
+      const float bias = P::round(bias2[jj]);
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(P::round(acc[jj][i] + bias), 0.f);
+      if (N.dropout) {
+        bool keep[4];
+        dropout_keep4(D, *Ap, step, 1, slab * 4 + q, col, keep);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = keep[i] ? P::round(v[i] * D.drop_scale) : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) h2[(4 * q + i) * HP + col] = P::from_f32(v[i]);
+      if (N.train_slot >= 0)
+        store4T<BF16>(reinterpret_cast<T *>(D.hT) + (size_t)(N.train_slot * 2 + 1) * H * D.BP +
+                          fidx<P>(col, slab * SLAB + 4 * q, D.BP / P::KM), v);
+    }
+  }
+  __syncthreads();
+  STAMP(0, 4);
+
   // ---- output layer: K split over the 4 waves, reduced through LDS ----
-  const int nt3 = N.out_pad / 16;  // 1 or 2
   {
     f32x4 acc3[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    const T *W3 = reinterpret_cast<const T *>(N.w3c);
-    for (int kb = wave * P::KM; kb < H; kb += 4 * P::KM) {
-      const uint4 a = *reinterpret_cast<const uint4 *>(h2 + r * HP + kb + P::EPV * q);
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
-        if (jt < nt3) {
-          const uint4 b = *reinterpret_cast<const uint4 *>(W3 + (size_t)(16 * jt + r) * H + kb + P::EPV * q);
-          P::mma(a, b, acc3[jt]);
-        }
+    for (int i = 0; i < K::NK3; ++i) {
+      const int ks = wave + 4 * i;
+      if (ks < K::NK2) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(h2 + r * HP + ks * P::KM + P::EPV * q);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+          if (jt < nt3) P::mma(a, w3[i][jt], acc3[jt]);
       }
     }
 #pragma unroll
@@ -184,185 +276,180 @@ __device__ __forceinline__ void mlp_slab(const FwdNet &N, const TrainerDesc &D, 
       if (jt < nt3) {
         f32x4 s = *reinterpret_cast<f32x4 *>(red + ((0 * 2 + jt) * 64 + lane) * 4);
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-          const f32x4 p = *reinterpret_cast<f32x4 *>(red + ((w * 2 + jt) * 64 + lane) * 4);
-          s += p;
-        }
+        for (int w = 1; w < 4; ++w) s += *reinterpret_cast<f32x4 *>(red + ((w * 2 + jt) * 64 + lane) * 4);
         const int col = 16 * jt + r;
         if (col < N.out_dim) {
-          const float bias = P::round(N.b3[col]);
+          const float bias = P::round(ldg(N.b3 + col));
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             float v = P::round(s[i] + bias);
             if (N.tanh_out) v = P::round(tanhf(v));
-            if (row0 + 4 * q + i < n_valid) out[(size_t)(row0 + 4 * q + i) * out_stride + N.out_col + col] = v;
+            if (row0 + 4 * q + i < n_valid)
+              stg(out + (size_t)(row0 + 4 * q + i) * out_stride + N.out_col + col, v);
           }
         }
       }
     }
   }
+  STAMP(0, 5);
 }
+
+__device__ __forceinline__ void write_adam_coef(const TrainerDesc &D, const DevArgs &A, int64_t t1,
+                                                AdamCoef *out);
 
 // ========================================================================
 // k_forward
 // ========================================================================
-template <bool BF16>
-__global__ __launch_bounds__(256) void k_forward(const TrainerDesc D, const DevArgs *__restrict__ Ap,
+template <bool BF16, int H>
+__global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__ Dp,
+                                                 const DevArgs *__restrict__ Ap,
                                                  const DevCtr *__restrict__ Cp) {
   using P = Prec<BF16>;
   using T = typename P::T;
-  const DevArgs &A = *Ap;
-  const int nslab = D.B / SLAB;
-  const int fnet = blockIdx.x / nslab, slab = blockIdx.x % nslab;
-  const FwdNet &N = D.fwd[fnet];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int H = D.H, HP = H + P::EPV, K1P = D.k1max + P::EPV;
-  const int tpw = H / 64;
+  // blocks are dealt round-robin over the 8 XCDs: keep all slabs of one network on one
+  // XCD so its weights are fetched into that L2 once (speed only, never correctness)
+  const int fnet = blockIdx.x & 7, slab = blockIdx.x >> 3;
+  const TrainerDesc &D = *Dp;
+  if (fnet >= N_FWD) {
+    // spare XCD slot: one thread prepares this step's Adam coefficients for k_update
+    if (slab == 0 && threadIdx.x == 0)
+      write_adam_coef(D, *Ap, Cp->ctr[0] + 1, const_cast<AdamCoef *>(&Cp->coef));
+    return;
+  }
+  const DevArgs A = *Ap;
+  const FwdNet N = D.fwd[fnet];
   const int64_t step = Cp->ctr[0];
-
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T *xs = reinterpret_cast<T *>(smem);             // [16][K1P]
-  T *h1 = xs + SLAB * K1P;                          // [16][HP]
-  T *h2 = h1 + SLAB * HP;                           // [16][HP]
-  float *red = reinterpret_cast<float *>(h2 + SLAB * HP);  // [4][2][64][4]
-  int64_t *sidx = reinterpret_cast<int64_t *>(red + 4 * 2 * 64 * 4);  // [16]
 
-  // ---- batch indices of this slab (ref:211-214) ----
-  if (tid < SLAB) {
-    const int row = slab * SLAB + tid;
+  auto fill = [&](T *xs, int K1P) {
+    const int tid = threadIdx.x;
+    // 16 lanes per row: batch index (ref:211-214), then the row's input segment
+    const int rr = tid >> 4, l16 = tid & 15;
+    const int row = slab * SLAB + rr;
     int64_t ix;
     if (A.idx_mode == 1)
-      ix = A.idx[(size_t)(step - A.base_step) * D.B + row];
+      ix = ldg(A.idx + (size_t)(step - A.base_step) * D.B + row);
     else if (A.idx_mode == 2)
       ix = row;
     else
       ix = philox_index(D.seed, (uint64_t)step, (uint32_t)row, (uint64_t)A.n_rows);
     ix = ix < 0 ? 0 : (ix >= A.n_rows ? A.n_rows - 1 : ix);
-    sidx[tid] = ix;
-  }
-  __syncthreads();
-
-  // ---- gather the slab's input rows into LDS (zero padded to k1pad) ----
-  const int k1 = N.k1pad;
-  for (int e = tid; e < SLAB * k1; e += 256) {
-    const int rr = e / k1, c = e - rr * k1;
-    float v = 0.f;
-    if (c < N.in_dim) v = A.rows[(size_t)sidx[rr] * A.row_stride + N.in_off + c];
-    xs[rr * K1P + c] = P::from_f32(v);
-    if (N.stage && c < N.in_dim)
-      reinterpret_cast<T *>(D.xT)[(size_t)c * D.BP + slab * SLAB + rr] = P::from_f32(v);
-  }
-  if (N.stage) {
-    const int sa = D.S + D.A;
-    if (tid < SLAB * 2) {
-      const int rr = tid >> 1, w = tid & 1;
-      D.rd[(size_t)(slab * SLAB + rr) * 2 + w] = A.rows[(size_t)sidx[rr] * A.row_stride + sa + w];
+    const float *src = A.rows + (size_t)ix * A.row_stride;
+    for (int c = l16; c < N.k1pad; c += 16) {
+      const float v = c < N.in_dim ? ldg(src + N.in_off + c) : 0.f;
+      const T tv = P::from_f32(v);
+      xs[rr * K1P + c] = tv;
+      if (N.stage && c < N.in_dim) stg(reinterpret_cast<T *>(D.xT) + fidx<P>(c, row, D.BP / P::KM), tv);
     }
-    for (int e = tid; e < SLAB * D.A; e += 256) {
-      const int rr = e / D.A, c = e - rr * D.A;
-      D.actf[(size_t)(slab * SLAB + rr) * D.A + c] = A.rows[(size_t)sidx[rr] * A.row_stride + D.S + c];
+    if (N.stage) {
+      const int sa = D.S + D.A;
+      if (l16 < 2) stg(D.rd + (size_t)row * 2 + l16, ldg(src + sa + l16));
+      for (int c = l16; c < D.A; c += 16) stg(D.actf + (size_t)row * D.A + c, ldg(src + D.S + c));
     }
-  }
-  __syncthreads();
-
-  mlp_slab<BF16>(N, D, Ap, step, slab, xs, h1, h2, red, D.outs, D.OUTW, (int64_t)slab * SLAB, D.B);
+  };
+  mlp_slab<BF16, H>(N, D, &A, step, slab, smem, D.outs, D.OUTW, (int64_t)slab * SLAB, D.B, fill);
 }
 
 // ========================================================================
 // k_infer: forward pass of one network on dense inputs (iqlhip_forward;
 // ref:452-543 forward()).  Rows beyond n are computed on zeros and not stored.
 // ========================================================================
-template <bool BF16>
-__global__ __launch_bounds__(256) void k_infer(const TrainerDesc D, const FwdNet N, const float *__restrict__ s,
+template <bool BF16, int H>
+__global__ __launch_bounds__(256) void k_infer(const TrainerDesc *__restrict__ Dp, const FwdNet N,
+                                               const float *__restrict__ s,
                                                const float *__restrict__ a, int64_t n, float *out,
                                                int out_stride) {
   using P = Prec<BF16>;
   using T = typename P::T;
-  const int tid = threadIdx.x;
-  const int H = D.H, HP = H + P::EPV, K1P = D.k1max + P::EPV;
+  const TrainerDesc &D = *Dp;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T *xs = reinterpret_cast<T *>(smem);
-  T *h1 = xs + SLAB * K1P;
-  T *h2 = h1 + SLAB * HP;
-  float *red = reinterpret_cast<float *>(h2 + SLAB * HP);
   const int64_t row0 = (int64_t)blockIdx.x * SLAB;
-  const int k1 = N.k1pad;
-  for (int e = tid; e < SLAB * k1; e += 256) {
-    const int rr = e / k1, c = e - rr * k1;
-    float v = 0.f;
-    if (row0 + rr < n && c < N.in_dim)
-      v = (c < D.S) ? s[(size_t)(row0 + rr) * D.S + c] : a[(size_t)(row0 + rr) * D.A + (c - D.S)];
-    xs[rr * K1P + c] = P::from_f32(v);
-  }
-  __syncthreads();
-  mlp_slab<BF16>(N, D, nullptr, 0, 0, xs, h1, h2, red, out, out_stride, row0, n);
+  auto fill = [&](T *xs, int K1P) {
+    const int k1 = N.k1pad;
+    for (int e = threadIdx.x; e < SLAB * k1; e += 256) {
+      const int rr = e / k1, c = e - rr * k1;
+      float v = 0.f;
+      if (row0 + rr < n && c < N.in_dim)
+        v = (c < D.S) ? ldg(s + (size_t)(row0 + rr) * D.S + c) : ldg(a + (size_t)(row0 + rr) * D.A + (c - D.S));
+      xs[rr * K1P + c] = P::from_f32(v);
+    }
+  };
+  mlp_slab<BF16, H>(N, D, nullptr, 0, 0, smem, out, out_stride, row0, n, fill);
 }
 
 // ========================================================================
 // k_backward
 // ========================================================================
-template <bool BF16>
-__global__ __launch_bounds__(256) void k_backward(const TrainerDesc D, const DevArgs *__restrict__ Ap,
-                                                  DevCtr *__restrict__ Cp) {
+template <bool BF16, int H>
+__global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict__ Dp,
+                                                  const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp) {
+  using K = KCfg<BF16, H>;
   using P = Prec<BF16>;
   using T = typename P::T;
-  const DevArgs &A = *Ap;
+  // XCD slot x = blockIdx & 7 serves network x/2: each network's slabs sit on two XCDs
+  const int xcd = blockIdx.x & 7, net = xcd >> 1;
+  const int slab = ((blockIdx.x >> 3) << 1) | (xcd & 1);
+  const TrainerDesc &D = *Dp;
   const int nslab = D.B / SLAB;
-  const int net = blockIdx.x / nslab, slab = blockIdx.x % nslab;
-  const TrainNet &N = D.net[net];
+  if (slab >= nslab) return;
+  const TrainNet N = D.net[net];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int H = D.H, HP = H + P::EPV, B = D.B, BP = D.BP;
-  const int tpw = H / 64;
+  constexpr int HP = K::HP, TPW = K::TPW;
+  const int B = D.B, BP = D.BP, nkb = D.BP / P::KM;
   const float fB = (float)B;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T *dz2s = reinterpret_cast<T *>(smem);                       // [16][HP]
-  float *dz3 = reinterpret_cast<float *>(dz2s + SLAB * HP);    // [16][32]
+  float *dz3 = reinterpret_cast<float *>(dz2s + SLAB * HP);    // [16][32] d(loss)/d(out)
   float *lterm = dz3 + SLAB * 32;                              // [16][32] loss terms
-  float *gstd = lterm + SLAB * 32;                             // [16][32]
-  float *eadv = gstd + SLAB * 32;                              // [16]
+  float *gstd = lterm + SLAB * 32;                             // [16][32] d(loss)/d(std) terms
+  float *rowsum = gstd + SLAB * 32;                            // [16]
 
   if (blockIdx.x == 0 && tid == 0) Cp->ctr[1] = Cp->ctr[0] + 1;
+  STAMP(1, 0);
+
+  // ---- request everything that does not depend on the loss ----
+  uint4 w2t[K::NKC][TPW];
+  load_w<P, K::NKC, TPW>(w2t, reinterpret_cast<const T *>(N.w2ct), K::NK2, 0, K::NKC, wave * TPW, lane);
+  float h1v[TPW][4];
+#pragma unroll
+  for (int jj = 0; jj < TPW; ++jj)
+    load4T<BF16>(reinterpret_cast<const T *>(D.hT) + (size_t)(net * 2 + 0) * H * BP +
+                     fidx<P>(16 * (wave * TPW + jj) + r, slab * SLAB + 4 * q, nkb),
+                 h1v[jj]);
+  const int c2 = tid;  // hidden unit this thread owns in the dZ2 phase
+  float h2v[16], w3v[32];
+  if (c2 < H) {
+    const T *h2T = reinterpret_cast<const T *>(D.hT) + (size_t)(net * 2 + 1) * H * BP;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      load4T<BF16>(h2T + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), &h2v[4 * g4]);
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      w3v[j] = j < N.out_dim
+                   ? P::to_f32(ldg(reinterpret_cast<const T *>(N.wc[2]) + fidx<P>(j, c2, K::NK2)))
+                   : 0.f;
+  }
 
   // ---- per-row loss terms and d(loss)/d(out)  (ref:581-637) ----
+  STAMP(1, 1);
   for (int e = tid; e < SLAB * 32; e += 256) dz3[e] = 0.f, lterm[e] = 0.f, gstd[e] = 0.f;
-  __syncthreads();
-  if (tid < SLAB) {
-    const int b = slab * SLAB + tid;
-    const float *o = D.outs + (size_t)b * D.OUTW;
-    const float adv = P::round(fminf(o[OUT_QT1], o[OUT_QT2]) - o[OUT_V]);  // ref:583-587
-    if (net == NET_V) {
-      const float w = fabsf(D.iql_tau - (adv < 0.f ? 1.f : 0.f));  // ref:404-405
-      lterm[tid * 32] = w * P::round(adv * adv);
-      float g;
-      if constexpr (BF16)
-        g = rbf(rbf(w / fB) * (2.f * adv));
-      else
-        g = (w / fB) * (2.f * adv);
-      dz3[tid * 32] = -g;  // adv = target_q - v
-    } else if (net == NET_A) {
-      eadv[tid] = fminf(P::round(expf(P::round(D.beta * adv))), 100.f);  // ref:622
-    } else {
-      const float rew = D.rd[(size_t)b * 2], done = D.rd[(size_t)b * 2 + 1];
-      const float target = rew + (1.f - done) * D.discount * o[OUT_NV];  // ref:604
-      const float diff = o[net == NET_Q1 ? OUT_Q1 : OUT_Q2] - target;
-      lterm[tid * 32] = diff * diff;
-      dz3[tid * 32] = P::round(diff / fB);  // 0.5 * 2 (q - t) / B
-    }
-  }
   __syncthreads();
   if (net == NET_A) {
     for (int e = tid; e < SLAB * D.A; e += 256) {
       const int rr = e / D.A, j = e - rr * D.A;
       const int b = slab * SLAB + rr;
-      const float mean = D.outs[(size_t)b * D.OUTW + OUT_MEAN + j];
-      const float act = D.actf[(size_t)b * D.A + j];
-      const float gbc = eadv[rr] / fB;
+      const float *o = D.outs + (size_t)b * D.OUTW;
+      const float qt1 = ldg(o + OUT_QT1), qt2 = ldg(o + OUT_QT2), vv = ldg(o + OUT_V);
+      const float mean = ldg(o + OUT_MEAN + j);
+      const float act = ldg(D.actf + (size_t)b * D.A + j);
+      float ls = D.deterministic ? 0.f : ldg(D.params + D.off_log_std + j);
+      const float adv = P::round(fminf(qt1, qt2) - vv);                       // ref:583-587
+      const float eadv = fminf(P::round(expf(P::round(D.beta * adv))), 100.f);  // ref:622
+      const float gbc = eadv / fB;
       float gm, bc;
       if (!D.deterministic) {
-        float ls = D.params[D.off_log_std + j];
         ls = fminf(fmaxf(ls, -20.f), 2.f);
         const float sd = expf(ls), var = sd * sd, z = act - mean;
         // -log_prob (torch.distributions.Normal.log_prob)
@@ -374,273 +461,454 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc D, const Dev
         bc = z * z;
         gm = P::round(gbc * 2.f * z);
       }
-      lterm[rr * 32 + j] = eadv[rr] * bc;
+      lterm[rr * 32 + j] = eadv * bc;
       dz3[rr * 32 + j] = P::round(gm * (1.f - mean * mean));  // tanh backward
     }
-    __syncthreads();
+  } else if (tid < SLAB) {
+    const int b = slab * SLAB + tid;
+    const float *o = D.outs + (size_t)b * D.OUTW;
+    const float qt1 = ldg(o + OUT_QT1), qt2 = ldg(o + OUT_QT2), vv = ldg(o + OUT_V), nv = ldg(o + OUT_NV);
+    const float qv = ldg(o + (net == NET_Q1 ? OUT_Q1 : OUT_Q2));
+    const float rew = ldg(D.rd + (size_t)b * 2), done = ldg(D.rd + (size_t)b * 2 + 1);
+    if (net == NET_V) {
+      const float adv = P::round(fminf(qt1, qt2) - vv);
+      const float w = fabsf(D.iql_tau - (adv < 0.f ? 1.f : 0.f));  // ref:404-405
+      lterm[tid * 32] = w * P::round(adv * adv);
+      float g;
+      if constexpr (BF16)
+        g = rbf(rbf(w / fB) * (2.f * adv));
+      else
+        g = (w / fB) * (2.f * adv);
+      dz3[tid * 32] = -g;  // adv = target_q - v
+    } else {
+      const float target = rew + (1.f - done) * D.discount * nv;  // ref:604
+      const float diff = qv - target;
+      lterm[tid * 32] = diff * diff;
+      dz3[tid * 32] = P::round(diff / fB);  // 0.5 * 2 (q - t) / B
+    }
   }
-  // per-slab partial sums (fixed order -> deterministic)
-  if (tid == 0) {
+  __syncthreads();
+  STAMP(1, 2);
+
+  // per-slab partial sums in a fixed order (deterministic): rows first, then the 16 row sums
+  if (tid < SLAB) {
     float s = 0.f;
-    for (int rr = 0; rr < SLAB; ++rr)
-      for (int j = 0; j < N.out_dim; ++j) s += lterm[rr * 32 + j];
-    D.lossp[net * nslab + slab] = s;
+    for (int j = 0; j < N.out_dim; ++j) s += lterm[tid * 32 + j];
+    rowsum[tid] = s;
   }
   if (net == NET_A && !D.deterministic && tid >= 64 && tid < 64 + D.A) {
     const int j = tid - 64;
     float s = 0.f;
+#pragma unroll
     for (int rr = 0; rr < SLAB; ++rr) s += gstd[rr * 32 + j];
-    D.lsp[(size_t)slab * D.A + j] = s;
+    stg(D.lsp + (size_t)slab * D.A + j, s);
   }
   // d(out), feature-major, for the layer-3 weight gradient
   for (int e = tid; e < N.out_dim * SLAB; e += 256) {
     const int j = e / SLAB, rr = e - j * SLAB;
-    reinterpret_cast<T *>(D.dz3T)[((size_t)net * D.opmax + j) * BP + slab * SLAB + rr] =
-        P::from_f32(dz3[rr * 32 + j]);
+    stg(reinterpret_cast<T *>(D.dz3T) + (size_t)net * D.opmax * BP + fidx<P>(j, slab * SLAB + rr, nkb),
+        P::from_f32(dz3[rr * 32 + j]));
   }
 
   // ---- dZ2 = (dZ3 W3) * relu'(h2)   (VALU: K = out_dim <= 32) ----
-  if (tid < H) {
-    const int c = tid;
-    const T *W3 = reinterpret_cast<const T *>(N.wc[2]);
-    const T *h2T = reinterpret_cast<const T *>(D.hT) + ((size_t)(net * 2 + 1) * H + c) * BP + slab * SLAB;
-    T *dst = reinterpret_cast<T *>(D.dz2T) + ((size_t)net * H + c) * BP + slab * SLAB;
+  if (c2 < H) {
+    T *dst = reinterpret_cast<T *>(D.dz2T) + (size_t)net * H * BP;
     float s[SLAB];
 #pragma unroll
     for (int rr = 0; rr < SLAB; ++rr) s[rr] = 0.f;
-    for (int j = 0; j < N.out_dim; ++j) {
-      const float w = P::to_f32(W3[(size_t)j * H + c]);
 #pragma unroll
-      for (int rr = 0; rr < SLAB; ++rr) s[rr] += dz3[rr * 32 + j] * w;
+    for (int j = 0; j < 32; ++j) {
+      if (j < N.out_dim) {
+#pragma unroll
+        for (int rr = 0; rr < SLAB; ++rr) s[rr] += dz3[rr * 32 + j] * w3v[j];
+      }
     }
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      float hv[4], outv[4];
-      load4T<BF16>(h2T + 4 * g4, hv);
+      float outv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rr = 4 * g4 + i;
         float sv = P::round(s[rr]);
         if (D.has_dropout && net == NET_A) sv = P::round(sv * D.drop_scale);
-        outv[i] = hv[i] > 0.f ? sv : 0.f;
-        dz2s[rr * HP + c] = P::from_f32(outv[i]);
+        outv[i] = h2v[rr] > 0.f ? sv : 0.f;
+        dz2s[rr * HP + c2] = P::from_f32(outv[i]);
       }
-      store4T<BF16>(dst + 4 * g4, outv);
+      store4T<BF16>(dst + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), outv);
     }
   }
   __syncthreads();
+  STAMP(1, 3);
+  if (tid == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < SLAB; ++rr) s += rowsum[rr];
+    stg(D.lossp + net * nslab + slab, s);
+  }
 
   // ---- dZ1 = (dZ2 W2) * relu'(h1)   (MFMA, B operand = transposed copy) ----
   {
-    f32x4 acc[MAXT];
+    f32x4 acc[TPW];
 #pragma unroll
-    for (int jj = 0; jj < MAXT; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    slab_gemm<BF16>(dz2s, HP, H, reinterpret_cast<const T *>(N.w2ct), tpw, wave, lane, acc);
+    for (int jj = 0; jj < TPW; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma_w<P, K::NKC, TPW>(dz2s, HP, 0, K::NKC, w2t, acc, lane);
+#pragma unroll 1
+    for (int ch = 1; ch < K::NCH; ++ch) {
+      load_w<P, K::NKC, TPW>(w2t, reinterpret_cast<const T *>(N.w2ct), K::NK2, ch * K::NKC, K::NKC,
+                             wave * TPW, lane);
+      mma_w<P, K::NKC, TPW>(dz2s, HP, ch * K::NKC * P::KM, K::NKC, w2t, acc, lane);
+    }
 #pragma unroll
-    for (int jj = 0; jj < MAXT; ++jj) {
-      if (jj < tpw) {
-        const int col = 16 * (wave * tpw + jj) + r;
-        const T *h1T = reinterpret_cast<const T *>(D.hT) + ((size_t)(net * 2 + 0) * H + col) * BP +
-                       slab * SLAB + 4 * q;
-        float hv[4], outv[4];
-        load4T<BF16>(h1T, hv);
+    for (int jj = 0; jj < TPW; ++jj) {
+      const int col = 16 * (wave * TPW + jj) + r;
+      float outv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float s = P::round(acc[jj][i]);
-          if (D.has_dropout && net == NET_A) s = P::round(s * D.drop_scale);
-          outv[i] = hv[i] > 0.f ? s : 0.f;
-        }
-        store4T<BF16>(reinterpret_cast<T *>(D.dz1T) + ((size_t)net * H + col) * BP + slab * SLAB + 4 * q,
-                      outv);
+      for (int i = 0; i < 4; ++i) {
+        float s = P::round(acc[jj][i]);
+        if (D.has_dropout && net == NET_A) s = P::round(s * D.drop_scale);
+        outv[i] = h1v[jj][i] > 0.f ? s : 0.f;
       }
+      store4T<BF16>(reinterpret_cast<T *>(D.dz1T) + (size_t)net * H * BP +
+                        fidx<P>(col, slab * SLAB + 4 * q, nkb), outv);
     }
   }
+  STAMP(1, 4);
 }
 
 // ========================================================================
 // k_update
 // ========================================================================
-struct AdamCoef {
-  float one_m_b1, b2, one_m_b2, neg_step[3], bc2_sqrt, eps;  // neg_step per group q / v / actor
-};
-
-__device__ __forceinline__ float adam_apply(float &p, float &m, float &v, float g, const AdamCoef &c,
-                                            float neg_step) {
+__device__ __forceinline__ void adam_apply(float &p, float &m, float &v, float g, const AdamCoef &c,
+                                           float neg_step) {
   m = m + (g - m) * c.one_m_b1;                 // exp_avg.lerp_(grad, 1 - beta1)
   v = v * c.b2 + (c.one_m_b2 * g) * g;          // mul_(beta2).addcmul_(g, g, 1 - beta2)
   const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
   p = p + neg_step * (m / denom);               // addcdiv_(exp_avg, denom, -step_size)
-  return p;
 }
 
+// beta^t by binary exponentiation (t <= 2^31): a few ulp, ~60 double multiplies
+__device__ __forceinline__ double ipow(double b, int64_t t) {
+  double r = 1.0;
+  while (t > 0) {
+    if (t & 1) r *= b;
+    b *= b;
+    t >>= 1;
+  }
+  return r;
+}
+
+// Adam bias corrections and the cosine actor lr of the step in flight (1-based
+// count t1), computed once by one thread of a spare k_forward block.
+__device__ __forceinline__ void write_adam_coef(const TrainerDesc &D, const DevArgs &A, int64_t t1,
+                                                AdamCoef *out) {
+  const double bc1 = 1.0 - ipow(D.beta1, t1);
+  const double bc2 = 1.0 - ipow(D.beta2, t1);
+  // CosineAnnealingLR closed form; t1-1 scheduler steps have been taken (ref:636-637)
+  const double lr_a = A.lr_a_base * (1.0 + cos(M_PI * (double)(t1 - 1) / (double)D.t_max)) * 0.5;
+  AdamCoef c;
+  c.one_m_b1 = (float)(1.0 - D.beta1);
+  c.b2 = (float)D.beta2;
+  c.one_m_b2 = (float)(1.0 - D.beta2);
+  c.neg_step[0] = (float)(-(A.lr_q / bc1));
+  c.neg_step[1] = (float)(-(A.lr_v / bc1));
+  c.neg_step[2] = (float)(-(lr_a / bc1));
+  c.bc2_sqrt = (float)sqrt(bc2);
+  c.eps = (float)D.eps;
+  *out = c;
+}
+
+constexpr int UKC = 8;  // batch k-steps per register chunk in the weight-gradient GEMM
+
+// One work-group owns the gradient tile dW[o0..o0+64)[i0..i0+64):
+//   1. every thread requests its share of the optimiser state (params, exp_avg,
+//      exp_avg_sq, target) in ROW order -- a wave instruction covers 4 rows x 256
+//      contiguous bytes of the torch [out][in] arrays, full 128-byte lines;
+//   2. wave w computes dW^T = X^T dZ for in-features [i0+16w, +16) x 64
+//      out-features on MFMA (A = layer input, B = dZ^T, both fragment-major);
+//   3. the tile goes through LDS so that step 1's row-ordered threads pick up
+//      their gradients, apply Adam + Polyak and stream the state back;
+//   4. the new weights go through LDS once more for the transposed compute copy.
+// Rows of the first layer are not 16-byte aligned (in_dim 29, 37, ...): that layer
+// uses a scalar path over the same tile.
+constexpr int UT = 64;        // tile edge
+constexpr int ULD = UT + 4;   // LDS row stride (floats)
+
 template <bool BF16>
-__global__ __launch_bounds__(256) void k_update(const TrainerDesc D, const DevArgs *__restrict__ Ap,
-                                                DevCtr *__restrict__ Cp,
+__global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ Dp,
+                                                const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
                                                 const UpdItem *__restrict__ items, int n_items) {
   using P = Prec<BF16>;
   using T = typename P::T;
+  const TrainerDesc &D = *Dp;
   const DevArgs &A = *Ap;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int H = D.H, B = D.B, BP = D.BP;
   const int nslab = B / SLAB;
   const int64_t t1 = Cp->ctr[1];  // 1-based Adam step of this update
+  const AdamCoef coef = Cp->coef;
 
-  __shared__ AdamCoef coef;
-  if (tid == 0) {
-    const double bc1 = 1.0 - pow(D.beta1, (double)t1);
-    const double bc2 = 1.0 - pow(D.beta2, (double)t1);
-    // CosineAnnealingLR closed form; t1-1 scheduler steps have been taken (ref:636-637)
-    const double lr_a = A.lr_a_base * (1.0 + cos(M_PI * (double)(t1 - 1) / (double)D.t_max)) * 0.5;
-    coef.one_m_b1 = (float)(1.0 - D.beta1);
-    coef.b2 = (float)D.beta2;
-    coef.one_m_b2 = (float)(1.0 - D.beta2);
-    coef.neg_step[0] = (float)(-(A.lr_q / bc1));
-    coef.neg_step[1] = (float)(-(A.lr_v / bc1));
-    coef.neg_step[2] = (float)(-(lr_a / bc1));
-    coef.bc2_sqrt = (float)sqrt(bc2);
-    coef.eps = (float)D.eps;
-  }
-  __syncthreads();
+  __shared__ __attribute__((aligned(16))) float tile[UT * ULD];  // [o][i] gradient, then new weights
+  __shared__ float bgrad[UT];
+  STAMP(2, 0);
 
   if ((int)blockIdx.x >= n_items) {
     // ---------------- misc block: log_std, logged losses, step counter ------------
+    // all partials are fetched in parallel, then summed in a fixed order from LDS
+    float *sred = tile;
+    const int nl = 4 * nslab, na = D.deterministic ? 0 : nslab * D.A;  // nl + na + 4 <= 1024 (host check)
+    for (int e = tid; e < nl + na; e += 256) sred[e] = e < nl ? ldg(D.lossp + e) : ldg(D.lsp + e - nl);
+    float ls = 0.f, pm = 0.f, pv = 0.f;
+    if (!D.deterministic && tid < D.A) {
+      const int64_t o = D.off_log_std + tid;
+      ls = ldg(D.params + o), pm = ldg(D.exp_avg + o), pv = ldg(D.exp_avg_sq + o);
+    }
+    __syncthreads();
     if (!D.deterministic && tid < D.A) {
       float g = 0.f;
-      for (int s = 0; s < nslab; ++s) g += D.lsp[(size_t)s * D.A + tid];
+      for (int s = 0; s < nslab; ++s) g += sred[nl + s * D.A + tid];
       const int64_t o = D.off_log_std + tid;
-      const float ls = D.params[o];
       const float lsc = fminf(fmaxf(ls, -20.f), 2.f);
       g = g * expf(lsc) * ((ls >= -20.f && ls <= 2.f) ? 1.f : 0.f);
-      float p = ls, m = D.exp_avg[o], v = D.exp_avg_sq[o];
-      adam_apply(p, m, v, g, coef, coef.neg_step[2]);
-      D.params[o] = p, D.exp_avg[o] = m, D.exp_avg_sq[o] = v;
-      if (D.grads) D.grads[o] = g;
+      float p = ls;
+      adam_apply(p, pm, pv, g, coef, coef.neg_step[2]);
+      stg(D.params + o, p), stg(D.exp_avg + o, pm), stg(D.exp_avg_sq + o, pv);
+      if (D.grads) stg(D.grads + o, g);
     }
+    if (tid >= 64 && tid < 68) {  // one lane per network: fixed-order sum of its slab partials
+      const int n = tid - 64;
+      float s = 0.f;
+      for (int k = 0; k < nslab; ++k) s += sred[n * nslab + k];
+      sred[nl + na + n] = s / (float)B;
+    }
+    __syncthreads();
     if (tid == 64) {
-      float s[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int n = 0; n < 4; ++n)
-        for (int k = 0; k < nslab; ++k) s[n] += D.lossp[n * nslab + k];
-      const float fB = (float)B;
-      const float vl = s[NET_V] / fB;
-      const float ql = (s[NET_Q1] / fB + s[NET_Q2] / fB) / 2.f;  // ref:606
-      const float al = s[NET_A] / fB;
+      const float vl = sred[nl + na + NET_V];
+      const float ql = (sred[nl + na + NET_Q1] + sred[nl + na + NET_Q2]) / 2.f;  // ref:606
+      const float al = sred[nl + na + NET_A];
       Cp->last_losses[0] = vl, Cp->last_losses[1] = ql, Cp->last_losses[2] = al;
       Cp->loss_sum[0] += vl, Cp->loss_sum[1] += ql, Cp->loss_sum[2] += al;
       if (A.losses_out) {
         float *lo = A.losses_out + (size_t)(t1 - 1 - A.base_step) * 3;
-        lo[0] = vl, lo[1] = ql, lo[2] = al;
+        stg(lo, vl), stg(lo + 1, ql), stg(lo + 2, al);
       }
       Cp->ctr[0] = t1;
     }
+    STAMP(2, 4);
     return;
   }
 
   const UpdItem it = items[blockIdx.x];
-  const TrainNet &N = D.net[it.net];
+  if (it.net < 0) return;  // padding slot of the XCD-major item table
   const int L = it.layer;
-  const int Odim = (L == 2) ? N.out_dim : H;
-  const int Idim = (L == 0) ? N.in_dim : H;
-  const int Kw = (L == 0) ? N.k1pad : H;  // row stride of the compute copy
+  const int Odim = it.Odim, Idim = it.Idim, Kw = it.Kw, Opad = it.Opad;
   const int Ipad = round_up(Idim, 16);
-  const int Opad = (L == 2) ? N.out_pad : H;
-  const int o_base = it.o0 + 16 * wave * it.wo;
-  const int i_base = it.i0 + 64 * wave * it.wi;
-  if (o_base >= Opad || i_base >= Ipad) return;
-  const float neg_step = coef.neg_step[it.net == NET_V ? 1 : (it.net == NET_A ? 2 : 0)];
+  const int o0 = it.o0, i0 = it.i0;
+  const bool vec = (Idim & 3) == 0;  // rows of the fp32 masters are 16-byte aligned
+  const float neg_step =
+      it.group == 0 ? coef.neg_step[0] : (it.group == 1 ? coef.neg_step[1] : coef.neg_step[2]);
+  const bool has_target = it.has_target != 0;
 
-  const T *Asrc = (L == 0) ? reinterpret_cast<const T *>(D.dz1T) + (size_t)it.net * H * BP
-                : (L == 1) ? reinterpret_cast<const T *>(D.dz2T) + (size_t)it.net * H * BP
-                           : reinterpret_cast<const T *>(D.dz3T) + (size_t)it.net * D.opmax * BP;
-  const T *Bsrc = (L == 0) ? reinterpret_cast<const T *>(D.xT)
-                           : reinterpret_cast<const T *>(D.hT) + (size_t)(it.net * 2 + (L - 1)) * H * BP;
-  const bool do_bias = (it.i0 == 0) && (it.wi == 0 || wave == 0);
-
-  f32x4 acc[4];
+  // ---- 1. optimiser state, row order: thread -> (row tr + 16 pass, columns 4 tc .. +3) ----
+  const int tr = tid >> 4, tc4 = (tid & 15) * 4;
+  float pw[4][4], mw[4][4], vw[4][4], tw[4][4];  // statically indexed only (registers, not scratch)
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
-  const T *arow = Asrc + (size_t)(o_base + r) * BP + P::EPV * q;
-  const T *brow = Bsrc + (size_t)(i_base + r) * BP + P::EPV * q;
-  for (int kb = 0; kb < BP; kb += P::KM) {
-    const uint4 a = *reinterpret_cast<const uint4 *>(arow + kb);
-    if (do_bias) {
-      if constexpr (BF16) {
-        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+  for (int ps = 0; ps < 4; ++ps) {
+    const int o = o0 + tr + 16 * ps, i = i0 + tc4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bsum += bf2f((uint16_t)(w[i] & 0xffff)) + bf2f((uint16_t)(w[i] >> 16));
+    for (int k = 0; k < 4; ++k) pw[ps][k] = mw[ps][k] = vw[ps][k] = tw[ps][k] = 0.f;
+#ifdef EXP_NOSTATE
+    if (false) {
+#else
+    if (o < Odim && i < Idim) {
+#endif
+      const int64_t e = it.off_w + (int64_t)o * Idim + i;
+      const int64_t te = it.toff_w + (int64_t)o * Idim + i;
+      if (vec) {
+        const float4 a4 = __builtin_bit_cast(float4, ldg16(D.params + e));
+        const float4 b4 = __builtin_bit_cast(float4, ldg16(D.exp_avg + e));
+        const float4 c4 = __builtin_bit_cast(float4, ldg16(D.exp_avg_sq + e));
+        pw[ps][0] = a4.x, pw[ps][1] = a4.y, pw[ps][2] = a4.z, pw[ps][3] = a4.w;
+        mw[ps][0] = b4.x, mw[ps][1] = b4.y, mw[ps][2] = b4.z, mw[ps][3] = b4.w;
+        vw[ps][0] = c4.x, vw[ps][1] = c4.y, vw[ps][2] = c4.z, vw[ps][3] = c4.w;
+        if (has_target) {
+          const float4 d4 = __builtin_bit_cast(float4, ldg16(D.target + te));
+          tw[ps][0] = d4.x, tw[ps][1] = d4.y, tw[ps][2] = d4.z, tw[ps][3] = d4.w;
+        }
       } else {
-        const float4 f = __builtin_bit_cast(float4, a);
-        bsum += (f.x + f.y) + (f.z + f.w);
-      }
-    }
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      if (i_base + 16 * jj < Ipad) {
-        const uint4 b = *reinterpret_cast<const uint4 *>(brow + (size_t)jj * 16 * BP + kb);
-        P::mma(a, b, acc[jj]);
-      }
-    }
-  }
-
-  // ---- Adam on the tile (gradient stays in registers) ----
-  float *Pm = D.params, *Mm = D.exp_avg, *Vm = D.exp_avg_sq;
-  T *wc = reinterpret_cast<T *>(N.wc[L]);
-  T *tc = N.has_target ? reinterpret_cast<T *>(N.tc[L]) : nullptr;
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int i = i_base + 16 * jj + r;
-    if (i_base + 16 * jj < Ipad && i < Idim) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int o = o_base + 4 * q + k;
-        if (o < Odim) {
-          const int64_t e = N.off_w[L] + (int64_t)o * Idim + i;
-          const float g = P::round(acc[jj][k]);
-          float p = Pm[e], m = Mm[e], v = Vm[e];
-          adam_apply(p, m, v, g, coef, neg_step);
-          Pm[e] = p, Mm[e] = m, Vm[e] = v;
-          if (D.grads) D.grads[e] = g;
-          wc[(size_t)o * Kw + i] = P::from_f32(p);
-          if (L == 1) reinterpret_cast<T *>(N.w2ct)[(size_t)i * H + o] = P::from_f32(p);
-          if (N.has_target) {
-            const int64_t te = N.toff_w[L] + (int64_t)o * Idim + i;
-            float tv = D.target[te];
-            tv = tv + D.tau * (p - tv);  // lerp_ (ref:127-129)
-            D.target[te] = tv;
-            tc[(size_t)o * Kw + i] = P::from_f32(tv);
+        for (int k = 0; k < 4; ++k) {
+          if (i + k < Idim) {
+            pw[ps][k] = ldg(D.params + e + k), mw[ps][k] = ldg(D.exp_avg + e + k);
+            vw[ps][k] = ldg(D.exp_avg_sq + e + k);
+            if (has_target) tw[ps][k] = ldg(D.target + te + k);
           }
         }
       }
     }
   }
-  // ---- bias gradient = row sums of dZ^T ----
-  if (do_bias) {
-    bsum += __shfl_xor(bsum, 16);
-    bsum += __shfl_xor(bsum, 32);
-    const int o = o_base + r;
-    if (q == 0 && o < Odim) {
-      const int64_t e = N.off_b[L] + o;
-      const float g = P::round(bsum);
-      float p = Pm[e], m = Mm[e], v = Vm[e];
-      adam_apply(p, m, v, g, coef, neg_step);
-      Pm[e] = p, Mm[e] = m, Vm[e] = v;
-      if (D.grads) D.grads[e] = g;
-      if (N.has_target) {
-        const int64_t te = N.toff_b[L] + o;
-        float tv = D.target[te];
-        tv = tv + D.tau * (p - tv);
-        D.target[te] = tv;
+  float pb = 0.f, mb = 0.f, vb = 0.f, tb = 0.f;
+  const bool do_bias = i0 == 0;
+  if (do_bias && tid < UT && o0 + tid < Odim) {
+    const int64_t eb = it.off_b + o0 + tid;
+    pb = ldg(D.params + eb), mb = ldg(D.exp_avg + eb), vb = ldg(D.exp_avg_sq + eb);
+    if (has_target) tb = ldg(D.target + it.toff_b + o0 + tid);
+  }
+  STAMP(2, 1);
+
+  // ---- 2. dW^T tile on MFMA: A = layer input X^T, B = dZ^T (fragment-major) ----
+  const T *Xsrc = reinterpret_cast<const T *>(it.Xsrc);
+  const T *Zsrc = reinterpret_cast<const T *>(it.Zsrc);
+  // wave (wo, wi) = (wave >> 1, wave & 1): in-feature tiles 2wi, 2wi+1 x out-feature tiles 2wo, 2wo+1
+  const int wo = wave >> 1, wi = wave & 1;
+  const int ib = i0 + 32 * wi, ob = o0 + 32 * wo;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+  const int nk = BP / P::KM;
+  const bool wave_bias = do_bias && wi == 0;
+  const bool xon[2] = {ib < Ipad, ib + 16 < Ipad};
+  const bool zon[2] = {ob < Opad, ob + 16 < Opad};
+#pragma unroll 1
+  for (int k0 = 0; k0 < nk; k0 += UKC) {
+    uint4 xf[UKC][2], zf[UKC][2];
+#pragma unroll
+    for (int ks = 0; ks < UKC; ++ks) {
+      if (k0 + ks < nk) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+          if (xon[a]) xf[ks][a] = ldg16(Xsrc + frag_off<P>((ib >> 4) + a, k0 + ks, nk, lane));
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          if (zon[b]) zf[ks][b] = ldg16(Zsrc + frag_off<P>((ob >> 4) + b, k0 + ks, nk, lane));
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < UKC; ++ks) {
+      if (k0 + ks < nk) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (zon[b]) {
+            if (wave_bias) {  // bias gradient = row sums of dZ^T (this lane: its out-feature, 1/4 of K)
+              if constexpr (BF16) {
+                const uint32_t w[4] = {zf[ks][b].x, zf[ks][b].y, zf[ks][b].z, zf[ks][b].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  bsum[b] += bf2f((uint16_t)(w[i] & 0xffff)) + bf2f((uint16_t)(w[i] >> 16));
+              } else {
+                const float4 f = __builtin_bit_cast(float4, zf[ks][b]);
+                bsum[b] += (f.x + f.y) + (f.z + f.w);
+              }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+              if (xon[a]) P::mma(xf[ks][a], zf[ks][b], acc[a][b]);
+          }
+        }
       }
     }
   }
+  // C/D layout: lane (r, q) of acc[a][b] holds dW[ob + 16 b + r][ib + 16 a + 4 q + k]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+      *reinterpret_cast<f32x4 *>(&tile[(32 * wo + 16 * b + r) * ULD + 32 * wi + 16 * a + 4 * q]) = acc[a][b];
+  if (wave_bias) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float bs = bsum[b];
+      bs += __shfl_xor(bs, 16);
+      bs += __shfl_xor(bs, 32);
+      if (q == 0) bgrad[32 * wo + 16 * b + r] = bs;
+    }
+  }
+  __syncthreads();
+  STAMP(2, 3);
+
+  // ---- 3. Adam + Polyak in row order; gradients come back from LDS ----
+  T *wc = reinterpret_cast<T *>(it.wc);
+  T *tc = reinterpret_cast<T *>(it.tc);
+  const int nkw = Kw / P::KM;
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int ol = tr + 16 * ps, o = o0 + ol, i = i0 + tc4;
+    const float4 g4 = *reinterpret_cast<const float4 *>(&tile[ol * ULD + tc4]);
+    float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    float p[4] = {pw[ps][0], pw[ps][1], pw[ps][2], pw[ps][3]};
+    float m[4] = {mw[ps][0], mw[ps][1], mw[ps][2], mw[ps][3]};
+    float v[4] = {vw[ps][0], vw[ps][1], vw[ps][2], vw[ps][3]};
+    float tv[4] = {tw[ps][0], tw[ps][1], tw[ps][2], tw[ps][3]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      g[k] = P::round(g[k]);
+      adam_apply(p[k], m[k], v[k], g[k], coef, neg_step);
+      if (has_target) tv[k] = tv[k] + D.tau * (p[k] - tv[k]);  // lerp_ (ref:127-129)
+    }
+    // the new weights replace this thread's gradients in the tile (step 4 reads them transposed)
+    if (L == 1) *reinterpret_cast<float4 *>(&tile[ol * ULD + tc4]) = make_float4(p[0], p[1], p[2], p[3]);
+    if (o < Odim && i < Idim) {
+      const int64_t e = it.off_w + (int64_t)o * Idim + i;
+      const int64_t te = it.toff_w + (int64_t)o * Idim + i;
+      if (vec) {
+        stg16(D.params + e, make_float4(p[0], p[1], p[2], p[3]));
+        stg16(D.exp_avg + e, make_float4(m[0], m[1], m[2], m[3]));
+        stg16(D.exp_avg_sq + e, make_float4(v[0], v[1], v[2], v[3]));
+        if (D.grads) stg16(D.grads + e, make_float4(g[0], g[1], g[2], g[3]));
+        if (has_target) stg16(D.target + te, make_float4(tv[0], tv[1], tv[2], tv[3]));
+        // 4 consecutive k of one row are contiguous in the fragment-major copies
+        store4T<BF16>(wc + fidx<P>(o, i, nkw), p);
+        if (has_target) store4T<BF16>(tc + fidx<P>(o, i, nkw), tv);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (i + k < Idim) {
+            stg(D.params + e + k, p[k]), stg(D.exp_avg + e + k, m[k]), stg(D.exp_avg_sq + e + k, v[k]);
+            if (D.grads) stg(D.grads + e + k, g[k]);
+            stg(wc + fidx<P>(o, i + k, nkw), P::from_f32(p[k]));
+            if (has_target) {
+              stg(D.target + te + k, tv[k]);
+              stg(tc + fidx<P>(o, i + k, nkw), P::from_f32(tv[k]));
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- bias: thread t < 64 owns out-feature o0 + t ----
+  if (do_bias && tid < UT && o0 + tid < Odim) {
+    const int64_t e = it.off_b + o0 + tid;
+    const float g = P::round(bgrad[tid]);
+    adam_apply(pb, mb, vb, g, coef, neg_step);
+    stg(D.params + e, pb), stg(D.exp_avg + e, mb), stg(D.exp_avg_sq + e, vb);
+    if (D.grads) stg(D.grads + e, g);
+    if (has_target) stg(D.target + it.toff_b + o0 + tid, tb + D.tau * (pb - tb));
+  }
+  // ---- 4. transposed compute copy of layer 2 for the backward GEMM: [in][out] ----
+  if (L == 1) {
+    __syncthreads();
+    // thread -> in-feature i0 + (tid >> 4) + 16 pass, out-features o0 + 4 (tid & 15) .. +3
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int il = tr + 16 * ps;
+      float pv4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pv4[k] = tile[(tc4 + k) * ULD + il];
+      store4T<BF16>(reinterpret_cast<T *>(it.w2ct) + fidx<P>(i0 + il, o0 + tc4, H / P::KM), pv4);
+    }
+  }
+  STAMP(2, 4);
 }
 
 // ========================================================================
 // k_sync_weights: rebuild every compute-precision copy from the fp32 masters
 // ========================================================================
 template <bool BF16>
-__global__ void k_sync_weights(const TrainerDesc D) {
+__global__ void k_sync_weights(const TrainerDesc *__restrict__ Dp) {
+  const TrainerDesc &D = *Dp;
   using P = Prec<BF16>;
   using T = typename P::T;
   const int net = blockIdx.y;
@@ -653,69 +921,83 @@ __global__ void k_sync_weights(const TrainerDesc D) {
     const int total = Odim * Idim;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
       const int o = e / Idim, i = e - o * Idim;
-      const float p = D.params[N.off_w[L] + e];
-      reinterpret_cast<T *>(N.wc[L])[(size_t)o * Kw + i] = P::from_f32(p);
-      if (L == 1) reinterpret_cast<T *>(N.w2ct)[(size_t)i * H + o] = P::from_f32(p);
+      const float p = ldg(D.params + N.off_w[L] + e);
+      stg(reinterpret_cast<T *>(N.wc[L]) + fidx<P>(o, i, Kw / P::KM), P::from_f32(p));
+      if (L == 1) stg(reinterpret_cast<T *>(N.w2ct) + fidx<P>(i, o, H / P::KM), P::from_f32(p));
       if (N.has_target)
-        reinterpret_cast<T *>(N.tc[L])[(size_t)o * Kw + i] = P::from_f32(D.target[N.toff_w[L] + e]);
+        stg(reinterpret_cast<T *>(N.tc[L]) + fidx<P>(o, i, Kw / P::KM),
+            P::from_f32(ldg(D.target + N.toff_w[L] + e)));
     }
   }
 }
 
-// explicit instantiations + launchers used by the host driver (api.hip)
+// ------------------------------------------------------------------------
+// launchers (host driver: api.hip)
+// ------------------------------------------------------------------------
 size_t fwd_smem_bytes(bool bf16, int H, int k1max) {
   const int es = bf16 ? 2 : 4, epv = bf16 ? 8 : 4;
-  return (size_t)SLAB * (k1max + epv) * es + 2 * (size_t)SLAB * (H + epv) * es + 4 * 2 * 64 * 4 * 4 +
-         SLAB * 8;
+  return (size_t)SLAB * (k1max + epv) * es + 2 * (size_t)SLAB * (H + epv) * es + 4 * 2 * 64 * 4 * 4;
 }
 size_t bwd_smem_bytes(bool bf16, int H) {
   const int es = bf16 ? 2 : 4, epv = bf16 ? 8 : 4;
   return (size_t)SLAB * (H + epv) * es + 3 * SLAB * 32 * 4 + SLAB * 4;
 }
 
-hipError_t launch_forward(bool bf16, const TrainerDesc &D, const DevArgs *a, const DevCtr *c,
-                          hipStream_t st) {
-  const int grid = N_FWD * (D.B / SLAB);
+#define DISPATCH_H(BF, HH, CALL)                 \
+  do {                                           \
+    if (BF) {                                    \
+      if (HH == 256) { CALL(true, 256); }        \
+      else if (HH == 128) { CALL(true, 128); }   \
+      else { CALL(true, 64); }                   \
+    } else {                                     \
+      if (HH == 256) { CALL(false, 256); }       \
+      else if (HH == 128) { CALL(false, 128); }  \
+      else { CALL(false, 64); }                  \
+    }                                            \
+  } while (0)
+
+hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
+                          const DevCtr *c, hipStream_t st) {
+  const int grid = 8 * (D.B / SLAB);
   const size_t sm = fwd_smem_bytes(bf16, D.H, D.k1max);
-  if (bf16)
-    hipLaunchKernelGGL(k_forward<true>, dim3(grid), dim3(256), sm, st, D, a, c);
-  else
-    hipLaunchKernelGGL(k_forward<false>, dim3(grid), dim3(256), sm, st, D, a, c);
+#define CALL(BF, HH) hipLaunchKernelGGL((k_forward<BF, HH>), dim3(grid), dim3(256), sm, st, dD, a, c)
+  DISPATCH_H(bf16, D.H, CALL);
+#undef CALL
   return hipGetLastError();
 }
-hipError_t launch_backward(bool bf16, const TrainerDesc &D, const DevArgs *a, DevCtr *c,
-                           hipStream_t st) {
-  const int grid = N_TRAIN * (D.B / SLAB);
+hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
+                           DevCtr *c, hipStream_t st) {
+  const int grid = 8 * ((D.B / SLAB + 1) / 2);
   const size_t sm = bwd_smem_bytes(bf16, D.H);
-  if (bf16)
-    hipLaunchKernelGGL(k_backward<true>, dim3(grid), dim3(256), sm, st, D, a, c);
-  else
-    hipLaunchKernelGGL(k_backward<false>, dim3(grid), dim3(256), sm, st, D, a, c);
+#define CALL(BF, HH) hipLaunchKernelGGL((k_backward<BF, HH>), dim3(grid), dim3(256), sm, st, dD, a, c)
+  DISPATCH_H(bf16, D.H, CALL);
+#undef CALL
   return hipGetLastError();
 }
-hipError_t launch_update(bool bf16, const TrainerDesc &D, const DevArgs *a, DevCtr *c,
+hipError_t launch_update(bool bf16, const TrainerDesc *dD, const DevArgs *a, DevCtr *c,
                          const UpdItem *items, int n_items, hipStream_t st) {
   if (bf16)
-    hipLaunchKernelGGL(k_update<true>, dim3(n_items + 1), dim3(256), 0, st, D, a, c, items, n_items);
+    hipLaunchKernelGGL(k_update<true>, dim3(n_items + 1), dim3(256), 0, st, dD, a, c, items, n_items);
   else
-    hipLaunchKernelGGL(k_update<false>, dim3(n_items + 1), dim3(256), 0, st, D, a, c, items, n_items);
+    hipLaunchKernelGGL(k_update<false>, dim3(n_items + 1), dim3(256), 0, st, dD, a, c, items, n_items);
   return hipGetLastError();
 }
-hipError_t launch_infer(bool bf16, const TrainerDesc &D, const FwdNet &N, const float *s, const float *a,
-                        int64_t n, float *out, int out_stride, hipStream_t st) {
+hipError_t launch_infer(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const FwdNet &N,
+                        const float *s, const float *a, int64_t n, float *out, int out_stride,
+                        hipStream_t st) {
   const int grid = (int)((n + SLAB - 1) / SLAB);
   const size_t sm = fwd_smem_bytes(bf16, D.H, D.k1max);
-  if (bf16)
-    hipLaunchKernelGGL(k_infer<true>, dim3(grid), dim3(256), sm, st, D, N, s, a, n, out, out_stride);
-  else
-    hipLaunchKernelGGL(k_infer<false>, dim3(grid), dim3(256), sm, st, D, N, s, a, n, out, out_stride);
+#define CALL(BF, HH) \
+  hipLaunchKernelGGL((k_infer<BF, HH>), dim3(grid), dim3(256), sm, st, dD, N, s, a, n, out, out_stride)
+  DISPATCH_H(bf16, D.H, CALL);
+#undef CALL
   return hipGetLastError();
 }
-hipError_t launch_sync_weights(bool bf16, const TrainerDesc &D, hipStream_t st) {
+hipError_t launch_sync_weights(bool bf16, const TrainerDesc *dD, hipStream_t st) {
   if (bf16)
-    hipLaunchKernelGGL(k_sync_weights<true>, dim3(32, N_TRAIN), dim3(256), 0, st, D);
+    hipLaunchKernelGGL(k_sync_weights<true>, dim3(32, N_TRAIN), dim3(256), 0, st, dD);
   else
-    hipLaunchKernelGGL(k_sync_weights<false>, dim3(32, N_TRAIN), dim3(256), 0, st, D);
+    hipLaunchKernelGGL(k_sync_weights<false>, dim3(32, N_TRAIN), dim3(256), 0, st, dD);
   return hipGetLastError();
 }
 
