@@ -285,11 +285,11 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
       per_xcd[2 * n + (k++ & 1)].push_back(it);
     };
     for (int o0 = 0; o0 < H; o0 += 64)
-      for (int i0 = 0; i0 < H; i0 += 64) put(1, o0, i0);
+      for (int i0 = 0; i0 < H; i0 += 32) put(1, o0, i0);
     for (int o0 = 0; o0 < H; o0 += 64)
-      for (int i0 = 0; i0 < round_up(indim[n], 16); i0 += 64) put(0, o0, i0);
+      for (int i0 = 0; i0 < round_up(indim[n], 16); i0 += 32) put(0, o0, i0);
     for (int o0 = 0; o0 < outpad[n]; o0 += 64)
-      for (int i0 = 0; i0 < H; i0 += 64) put(2, o0, i0);
+      for (int i0 = 0; i0 < H; i0 += 32) put(2, o0, i0);
   }
   size_t depth = 0;
   for (auto &v : per_xcd) depth = v.size() > depth ? v.size() : depth;

@@ -145,10 +145,10 @@ __device__ __forceinline__ void dropout_keep4(const TrainerDesc &D, const DevArg
 // input rows into LDS; it runs AFTER the weight fragments of all three layers
 // have been requested, so the replay gather overlaps the weight fetch.
 // ------------------------------------------------------------------------
-template <bool BF16, int H, class Fill>
+template <bool BF16, int H, class Issue, class Fill>
 __device__ __forceinline__ void mlp_slab(const FwdNet &N, const TrainerDesc &D, const DevArgs *Ap,
                                          int64_t step, int slab, char *smem, float *out, int out_stride,
-                                         int64_t row0, int64_t n_valid, Fill fill) {
+                                         int64_t row0, int64_t n_valid, Issue issue, Fill fill) {
   using K = KCfg<BF16, H>;
   using P = Prec<BF16>;
   using T = typename P::T;
@@ -162,6 +162,9 @@ __device__ __forceinline__ void mlp_slab(const FwdNet &N, const TrainerDesc &D, 
   float *red = reinterpret_cast<float *>(h2 + SLAB * HP);   // [4][2][64][4]
 
   STAMP(0, 0);
+  // the input rows first: loads return in order, so the gather must not queue behind
+  // the 160 KB of weight fragments requested next
+  issue();
   // ---- request every weight fragment this wave will need ----
   const int nk1 = N.k1pad / P::KM;
   const int nt3 = N.out_pad / 16;  // 1 or 2
@@ -321,11 +324,12 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   const int64_t step = Cp->ctr[0];
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  auto fill = [&](T *xs, int K1P) {
-    const int tid = threadIdx.x;
-    // 16 lanes per row: batch index (ref:211-214), then the row's input segment
-    const int rr = tid >> 4, l16 = tid & 15;
-    const int row = slab * SLAB + rr;
+  // 16 lanes per row: batch index (ref:211-214), then the row's input segment
+  const int rr = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+  const int row = slab * SLAB + rr;
+  constexpr int NXV = 8;  // k1pad <= 128 -> at most 8 elements per lane
+  float xv[NXV], av[2], rdv = 0.f;
+  auto issue = [&]() {
     int64_t ix;
     if (A.idx_mode == 1)
       ix = ldg(A.idx + (size_t)(step - A.base_step) * D.B + row);
@@ -335,19 +339,35 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
       ix = philox_index(D.seed, (uint64_t)step, (uint32_t)row, (uint64_t)A.n_rows);
     ix = ix < 0 ? 0 : (ix >= A.n_rows ? A.n_rows - 1 : ix);
     const float *src = A.rows + (size_t)ix * A.row_stride;
-    for (int c = l16; c < N.k1pad; c += 16) {
-      const float v = c < N.in_dim ? ldg(src + N.in_off + c) : 0.f;
-      const T tv = P::from_f32(v);
-      xs[rr * K1P + c] = tv;
-      if (N.stage && c < N.in_dim) stg(reinterpret_cast<T *>(D.xT) + fidx<P>(c, row, D.BP / P::KM), tv);
+#pragma unroll
+    for (int j = 0; j < NXV; ++j) {
+      const int c = l16 + 16 * j;
+      xv[j] = c < N.in_dim ? ldg(src + N.in_off + c) : 0.f;
     }
     if (N.stage) {
-      const int sa = D.S + D.A;
-      if (l16 < 2) stg(D.rd + (size_t)row * 2 + l16, ldg(src + sa + l16));
-      for (int c = l16; c < D.A; c += 16) stg(D.actf + (size_t)row * D.A + c, ldg(src + D.S + c));
+      if (l16 < 2) rdv = ldg(src + D.S + D.A + l16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) av[j] = l16 + 16 * j < D.A ? ldg(src + D.S + l16 + 16 * j) : 0.f;
     }
   };
-  mlp_slab<BF16, H>(N, D, &A, step, slab, smem, D.outs, D.OUTW, (int64_t)slab * SLAB, D.B, fill);
+  auto fill = [&](T *xs, int K1P) {
+#pragma unroll
+    for (int j = 0; j < NXV; ++j) {
+      const int c = l16 + 16 * j;
+      if (c < N.k1pad) {
+        const T tv = P::from_f32(xv[j]);
+        xs[rr * K1P + c] = tv;
+        if (N.stage && c < N.in_dim) stg(reinterpret_cast<T *>(D.xT) + fidx<P>(c, row, D.BP / P::KM), tv);
+      }
+    }
+    if (N.stage) {
+      if (l16 < 2) stg(D.rd + (size_t)row * 2 + l16, rdv);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (l16 + 16 * j < D.A) stg(D.actf + (size_t)row * D.A + l16 + 16 * j, av[j]);
+    }
+  };
+  mlp_slab<BF16, H>(N, D, &A, step, slab, smem, D.outs, D.OUTW, (int64_t)slab * SLAB, D.B, issue, fill);
 }
 
 // ========================================================================
@@ -374,7 +394,7 @@ __global__ __launch_bounds__(256) void k_infer(const TrainerDesc *__restrict__ D
       xs[rr * K1P + c] = P::from_f32(v);
     }
   };
-  mlp_slab<BF16, H>(N, D, nullptr, 0, 0, smem, out, out_stride, row0, n, fill);
+  mlp_slab<BF16, H>(N, D, nullptr, 0, 0, smem, out, out_stride, row0, n, [] {}, fill);
 }
 
 // ========================================================================
@@ -619,19 +639,25 @@ __device__ __forceinline__ void write_adam_coef(const TrainerDesc &D, const DevA
 
 constexpr int UKC = 8;  // batch k-steps per register chunk in the weight-gradient GEMM
 
-// One work-group owns the gradient tile dW[o0..o0+64)[i0..i0+64):
+// One work-group owns the gradient tile dW[o0..o0+64)[i0..i0+32) (192 work-groups
+// at H = 256: the optimiser state is THE streaming traffic of the step and a CU
+// pulls only ~30 GB/s from the Infinity Cache, so it is spread over most CUs):
 //   1. every thread requests its share of the optimiser state (params, exp_avg,
-//      exp_avg_sq, target) in ROW order -- a wave instruction covers 4 rows x 256
-//      contiguous bytes of the torch [out][in] arrays, full 128-byte lines;
-//   2. wave w computes dW^T = X^T dZ for in-features [i0+16w, +16) x 64
-//      out-features on MFMA (A = layer input, B = dZ^T, both fragment-major);
+//      exp_avg_sq, target) in ROW order -- a wave instruction covers 8 rows x one
+//      full 128-byte line of the torch [out][in] arrays;
+//   2. wave w computes dW^T = X^T dZ for one 16-wide in-feature tile x two
+//      out-feature tiles on MFMA (A = layer input, B = dZ^T, fragment-major);
 //   3. the tile goes through LDS so that step 1's row-ordered threads pick up
 //      their gradients, apply Adam + Polyak and stream the state back;
 //   4. the new weights go through LDS once more for the transposed compute copy.
 // Rows of the first layer are not 16-byte aligned (in_dim 29, 37, ...): that layer
 // uses a scalar path over the same tile.
-constexpr int UT = 64;        // tile edge
-constexpr int ULD = UT + 4;   // LDS row stride (floats)
+constexpr int UTO = 64;          // tile: out-features
+constexpr int UTI = 32;          // tile: in-features
+constexpr int ULD = UTI + 4;     // LDS row stride (floats)
+constexpr int UTPR = UTI / 4;    // threads per tile row (float4 each)
+constexpr int URPP = 256 / UTPR; // rows per pass
+constexpr int UNP = UTO / URPP;  // passes
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ Dp,
@@ -648,8 +674,9 @@ __global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ 
   const int64_t t1 = Cp->ctr[1];  // 1-based Adam step of this update
   const AdamCoef coef = Cp->coef;
 
-  __shared__ __attribute__((aligned(16))) float tile[UT * ULD];  // [o][i] gradient, then new weights
-  __shared__ float bgrad[UT];
+  __shared__ __attribute__((aligned(16))) float tile[UTO * ULD];  // [o][i] gradient, then new weights
+  __shared__ float bgrad[UTO];
+  static_assert(UTO * ULD >= 1024, "the misc block reuses the tile as its reduction buffer");
   STAMP(2, 0);
 
   if ((int)blockIdx.x >= n_items) {
@@ -710,18 +737,14 @@ __global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ 
   const bool has_target = it.has_target != 0;
 
   // ---- 1. optimiser state, row order: thread -> (row tr + 16 pass, columns 4 tc .. +3) ----
-  const int tr = tid >> 4, tc4 = (tid & 15) * 4;
-  float pw[4][4], mw[4][4], vw[4][4], tw[4][4];  // statically indexed only (registers, not scratch)
+  const int tr = tid / UTPR, tc4 = (tid % UTPR) * 4;
+  float pw[UNP][4], mw[UNP][4], vw[UNP][4], tw[UNP][4];  // statically indexed only (registers)
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
-    const int o = o0 + tr + 16 * ps, i = i0 + tc4;
+  for (int ps = 0; ps < UNP; ++ps) {
+    const int o = o0 + tr + URPP * ps, i = i0 + tc4;
 #pragma unroll
     for (int k = 0; k < 4; ++k) pw[ps][k] = mw[ps][k] = vw[ps][k] = tw[ps][k] = 0.f;
-#ifdef EXP_NOSTATE
-    if (false) {
-#else
     if (o < Odim && i < Idim) {
-#endif
       const int64_t e = it.off_w + (int64_t)o * Idim + i;
       const int64_t te = it.toff_w + (int64_t)o * Idim + i;
       if (vec) {
@@ -749,7 +772,7 @@ __global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ 
   }
   float pb = 0.f, mb = 0.f, vb = 0.f, tb = 0.f;
   const bool do_bias = i0 == 0;
-  if (do_bias && tid < UT && o0 + tid < Odim) {
+  if (do_bias && tid < UTO && o0 + tid < Odim) {
     const int64_t eb = it.off_b + o0 + tid;
     pb = ldg(D.params + eb), mb = ldg(D.exp_avg + eb), vb = ldg(D.exp_avg_sq + eb);
     if (has_target) tb = ldg(D.target + it.toff_b + o0 + tid);
@@ -759,31 +782,26 @@ __global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ 
   // ---- 2. dW^T tile on MFMA: A = layer input X^T, B = dZ^T (fragment-major) ----
   const T *Xsrc = reinterpret_cast<const T *>(it.Xsrc);
   const T *Zsrc = reinterpret_cast<const T *>(it.Zsrc);
-  // wave (wo, wi) = (wave >> 1, wave & 1): in-feature tiles 2wi, 2wi+1 x out-feature tiles 2wo, 2wo+1
+  // wave (wo, wi) = (wave >> 1, wave & 1): in-feature tile wi x out-feature tiles 2wo, 2wo+1
   const int wo = wave >> 1, wi = wave & 1;
-  const int ib = i0 + 32 * wi, ob = o0 + 32 * wo;
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ib = i0 + 16 * wi, ob = o0 + 32 * wo;
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   float bsum[2] = {0.f, 0.f};
   const int nk = BP / P::KM;
   const bool wave_bias = do_bias && wi == 0;
-  const bool xon[2] = {ib < Ipad, ib + 16 < Ipad};
+  const bool xon = ib < Ipad;
   const bool zon[2] = {ob < Opad, ob + 16 < Opad};
 #pragma unroll 1
   for (int k0 = 0; k0 < nk; k0 += UKC) {
-    uint4 xf[UKC][2], zf[UKC][2];
+    uint4 xf[UKC], zf[UKC][2];
 #pragma unroll
     for (int ks = 0; ks < UKC; ++ks) {
       if (k0 + ks < nk) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-          if (xon[a]) xf[ks][a] = ldg16(Xsrc + frag_off<P>((ib >> 4) + a, k0 + ks, nk, lane));
+        if (xon) xf[ks] = ldg16(Xsrc + frag_off<P>(ib >> 4, k0 + ks, nk, lane));
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          if (zon[b]) zf[ks][b] = ldg16(Zsrc + frag_off<P>((ob >> 4) + b, k0 + ks, nk, lane));
+          if (zon[b] && (xon || wave_bias))
+            zf[ks][b] = ldg16(Zsrc + frag_off<P>((ob >> 4) + b, k0 + ks, nk, lane));
       }
     }
 #pragma unroll
@@ -803,20 +821,16 @@ __global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ 
                 bsum[b] += (f.x + f.y) + (f.z + f.w);
               }
             }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-              if (xon[a]) P::mma(xf[ks][a], zf[ks][b], acc[a][b]);
+            if (xon) P::mma(xf[ks], zf[ks][b], acc[b]);
           }
         }
       }
     }
   }
-  // C/D layout: lane (r, q) of acc[a][b] holds dW[ob + 16 b + r][ib + 16 a + 4 q + k]
+  // C/D layout: lane (r, q) of acc[b] holds dW[ob + 16 b + r][ib + 4 q + k]
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-      *reinterpret_cast<f32x4 *>(&tile[(32 * wo + 16 * b + r) * ULD + 32 * wi + 16 * a + 4 * q]) = acc[a][b];
+  for (int b = 0; b < 2; ++b)
+    *reinterpret_cast<f32x4 *>(&tile[(32 * wo + 16 * b + r) * ULD + 16 * wi + 4 * q]) = acc[b];
   if (wave_bias) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -834,8 +848,8 @@ __global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ 
   T *tc = reinterpret_cast<T *>(it.tc);
   const int nkw = Kw / P::KM;
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
-    const int ol = tr + 16 * ps, o = o0 + ol, i = i0 + tc4;
+  for (int ps = 0; ps < UNP; ++ps) {
+    const int ol = tr + URPP * ps, o = o0 + ol, i = i0 + tc4;
     const float4 g4 = *reinterpret_cast<const float4 *>(&tile[ol * ULD + tc4]);
     float g[4] = {g4.x, g4.y, g4.z, g4.w};
     float p[4] = {pw[ps][0], pw[ps][1], pw[ps][2], pw[ps][3]};
@@ -879,7 +893,7 @@ __global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ 
     }
   }
   // ---- bias: thread t < 64 owns out-feature o0 + t ----
-  if (do_bias && tid < UT && o0 + tid < Odim) {
+  if (do_bias && tid < UTO && o0 + tid < Odim) {
     const int64_t e = it.off_b + o0 + tid;
     const float g = P::round(bgrad[tid]);
     adam_apply(pb, mb, vb, g, coef, neg_step);
@@ -892,12 +906,12 @@ __global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ 
     __syncthreads();
     // thread -> in-feature i0 + (tid >> 4) + 16 pass, out-features o0 + 4 (tid & 15) .. +3
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int il = tr + 16 * ps;
+    for (int ps = 0; ps < UTI / 16; ++ps) {
+      const int il = (tid >> 4) + 16 * ps, o4 = (tid & 15) * 4;
       float pv4[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) pv4[k] = tile[(tc4 + k) * ULD + il];
-      store4T<BF16>(reinterpret_cast<T *>(it.w2ct) + fidx<P>(i0 + il, o0 + tc4, H / P::KM), pv4);
+      for (int k = 0; k < 4; ++k) pv4[k] = tile[(o4 + k) * ULD + il];
+      store4T<BF16>(reinterpret_cast<T *>(it.w2ct) + fidx<P>(i0 + il, o0 + o4, H / P::KM), pv4);
     }
   }
   STAMP(2, 4);

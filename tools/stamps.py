@@ -67,3 +67,9 @@ if "--detail" in sys.argv:
     for b in np.where(used)[0]:
         row = [(w[b, s] - t0) * 10 if w[b, s] > 0 else -1 for s in range(5)]
         print(f"upd block {b:3d} xcd {b % 8}: " + " ".join(f"{x:7.0f}" for x in row))
+
+# the misc block of k_update is the last block of its grid
+w = d[2, :, :, 0]
+used = np.where(w[:, 0] > 0)[0]
+mb = used.max()
+print(f"k_update misc block {mb}: start +{(w[mb,0]-w[used,0].min())*10:.0f} ns, duration {(w[mb,4]-w[mb,0])*10:.0f} ns")
