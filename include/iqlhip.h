@@ -179,6 +179,55 @@ typedef struct {
 int iqlhip_mlp_forward(const iqlhip_mlp_desc *d, const float *x, int64_t n, int32_t x_stride,
                        float *out, int32_t out_stride, void *stream);
 
+/* ------------------------------------------------------------------------ */
+/* Ensemble CVaR  (ref:1003-1011 BNN, ref:1185-1187 MR snapshots)             */
+/*   out[c] = mean of the n_tail smallest of preds[0..S)[c],  c < N           */
+/* preds: device fp32 [S][N] row-major (one row per posterior sample /         */
+/* snapshot, filled with iqlhip_mlp_forward using out_stride = 1 into row k). */
+/* n_tail = max(1, floor((1 - alpha) S)) (ref:935,1152); S <= 2400.           */
+/* ------------------------------------------------------------------------ */
+int iqlhip_cvar_tail_mean(const float *preds, int32_t S, int64_t N, int32_t n_tail, float *out,
+                          void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Preference-transformer relabel  (ref:1223-1309 qlearning_dataset_pt)        */
+/* Architecture: reward_models/pref_transformer.py:170-277 (PT), ops.py:6-117.  */
+/* One GPT-2 block, embd_dim 64.  Every pointer is device fp32; "T" = stored   */
+/* transposed ([in][out]) relative to the torch / state-dict [out][in] layout. */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  int32_t state_dim, action_dim;
+  int32_t embd_dim;   /* must be 64                                             */
+  int32_t num_heads;  /* power of two <= 16                                     */
+  int32_t inter_dim;  /* GPT2MLP width, multiple of 64, <= 1024                 */
+  int32_t num_layers; /* must be 1                                              */
+  int32_t n_temb;     /* rows of timestep_embed (max_episode_steps + 1)         */
+  float eps;          /* LayerNorm epsilon                                      */
+  const float *state_wT, *state_b;   /* state_linear  [S][64] T, [64]          */
+  const float *action_wT, *action_b; /* action_linear [A][64] T, [64]          */
+  const float *temb;                 /* timestep_embed.weight [n_temb][64]     */
+  const float *sln_w, *sln_b;        /* stacked_layer_norm                     */
+  const float *ln0_w, *ln0_b;        /* gpt.layers.0.layer_norm_0              */
+  const float *qkv_w, *qkv_b;        /* attention.in_linear [192][64], [192]   */
+  const float *q_wT;                 /* rows 0..63 of qkv_w, transposed [64][64]*/
+  const float *attn_out_wT, *attn_out_b; /* attention.out_linear [64][64] T    */
+  const float *ln1_w, *ln1_b;        /* layer_norm_1                           */
+  const float *mlp_in_wT, *mlp_in_b;   /* mlp.in_linear  [64][I] T, [I]        */
+  const float *mlp_out_wT, *mlp_out_b; /* mlp.out_linear [I][64] T, [64]       */
+  const float *lnf_w, *lnf_b;        /* gpt.layer_norm                         */
+  const float *pref_w_last;          /* LAST row of pref_linear.weight [64]    */
+  float pref_b_last;                 /* last element of pref_linear.bias       */
+} iqlhip_pt_weights;
+
+/* out[w] = value[:, 0, -1, 0] (ref:1301) of the window of win_len[w] consecutive
+ * transitions obs/act[win_start[w] .. +win_len[w]), right-aligned in a
+ * query_length window with timesteps 0..len-1 (ref:1269-1292).
+ * obs [n_rows][S], act [n_rows][A], win_start int64 [n_win], win_len int32
+ * [n_win] (1 <= len <= query_length), all device.                            */
+int iqlhip_pt_relabel(const iqlhip_pt_weights *w, const float *obs, const float *act, int64_t n_rows,
+                      const int64_t *win_start, const int32_t *win_len, int64_t n_win,
+                      int32_t query_length, float *out, void *stream);
+
 /* Algorithmic traffic and work of one step for this configuration
  * (SURVEY.md section 8d): bytes = 4B(2S+A+2) + 32 P_train + 8 P_q.          */
 int iqlhip_step_cost(const iqlhip_trainer_config *cfg, double *bytes, double *flops);

@@ -8,3 +8,7 @@ from .iql import (  # noqa: F401
     ImplicitQLearning, ReplayBuffer, Squeeze, TrainConfig, TwinQ, ValueFunction,
     asymmetric_l2_loss, compute_mean_std, load_config, mlp_forward_f32, normalize_states,
     set_seed, soft_update)
+from .relabel import (  # noqa: F401,E402
+    RewardMLP, RewardPT, cvar_stability_check, empirical_cvar, keep_mask_and_steps,
+    load_mlp_reward_model, load_pt_reward_model, modify_reward, qlearning_dataset_bnn,
+    qlearning_dataset_mr, qlearning_dataset_mr_ensemble, qlearning_dataset_pt, return_reward_range)

@@ -51,6 +51,18 @@ class MlpDesc(C.Structure):
                 ("w_in_out", C.c_int32), ("hidden_act", C.c_int32), ("out_act", C.c_int32)]
 
 
+class PtWeights(C.Structure):
+    _fields_ = ([("state_dim", C.c_int32), ("action_dim", C.c_int32), ("embd_dim", C.c_int32),
+                 ("num_heads", C.c_int32), ("inter_dim", C.c_int32), ("num_layers", C.c_int32),
+                 ("n_temb", C.c_int32), ("eps", C.c_float)] +
+                [(n, C.c_void_p) for n in (
+                    "state_wT", "state_b", "action_wT", "action_b", "temb", "sln_w", "sln_b",
+                    "ln0_w", "ln0_b", "qkv_w", "qkv_b", "q_wT", "attn_out_wT", "attn_out_b",
+                    "ln1_w", "ln1_b", "mlp_in_wT", "mlp_in_b", "mlp_out_wT", "mlp_out_b",
+                    "lnf_w", "lnf_b", "pref_w_last")] +
+                [("pref_b_last", C.c_float)])
+
+
 # every symbol include/iqlhip.h declares: name -> (restype, argtypes)
 P = C.c_void_p
 SYMBOLS = {
@@ -73,6 +85,9 @@ SYMBOLS = {
     "iqlhip_train_batch": (C.c_int, [P, P, P, P, P, P, P, P, P]),
     "iqlhip_forward": (C.c_int, [P, C.c_int32, P, P, C.c_int64, P, P]),
     "iqlhip_mlp_forward": (C.c_int, [C.POINTER(MlpDesc), P, C.c_int64, C.c_int32, P, C.c_int32, P]),
+    "iqlhip_cvar_tail_mean": (C.c_int, [P, C.c_int32, C.c_int64, C.c_int32, P, P]),
+    "iqlhip_pt_relabel": (C.c_int, [C.POINTER(PtWeights), P, P, C.c_int64, P, P, C.c_int64, C.c_int32,
+                                    P, P]),
     "iqlhip_step_cost": (C.c_int, [C.POINTER(TrainerConfig), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),
     "iqlhip_trainer_set_timing": (C.c_int, [P, C.c_int32]),

@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["api.hip", "iql_step.hip", "buffer.hip", "mlp_f32.hip"]
+SOURCES = ["api.hip", "iql_step.hip", "buffer.hip", "mlp_f32.hip", "cvar.hip", "pt.hip"]
 LIB = os.path.join(HERE, "libiqlhip.so")
 
 

@@ -34,6 +34,11 @@ hipError_t launch_sample(const iqlhip_replay_view &v, int batch, const int64_t *
                          int64_t *idx_out, hipStream_t st);
 hipError_t launch_mlp_f32(const iqlhip_mlp_desc &d, const float *x, int64_t n, int x_stride, float *out,
                           int out_stride, hipStream_t st);
+hipError_t launch_cvar(const float *preds, int S, int64_t N, int n_tail, float *out, hipStream_t st);
+size_t pt_smem_bytes(const iqlhip_pt_weights &W, int ql);
+hipError_t launch_pt(const iqlhip_pt_weights &W, const float *obs, const float *act, int64_t n_rows,
+                     const int64_t *win_start, const int32_t *win_len, int64_t n_win, int ql, float *out,
+                     hipStream_t st);
 }  // namespace iqlhip
 
 using namespace iqlhip;
@@ -628,5 +633,35 @@ extern "C" int iqlhip_trainer_set_debug(iqlhip_trainer *t, void *buf) {
     (void)hipGraphExecDestroy(t->gexec);
     t->gexec = nullptr;
   }
+  return 0;
+}
+
+extern "C" int iqlhip_cvar_tail_mean(const float *preds, int32_t S, int64_t N, int32_t n_tail, float *out,
+                                     void *stream) {
+  if (!preds || !out) return fail(IQLHIP_ERR_INVALID, "null argument");
+  if (S < 1 || N < 1) return fail(IQLHIP_ERR_INVALID, "S and N must be positive");
+  if (n_tail < 1 || n_tail > S) return fail(IQLHIP_ERR_INVALID, "n_tail must be in [1, S]");
+  if (S > 2400) return fail(IQLHIP_ERR_UNSUPPORTED, "S = %d > 2400", S);
+  HIP_TRY(launch_cvar(preds, S, N, n_tail, out, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int iqlhip_pt_relabel(const iqlhip_pt_weights *w, const float *obs, const float *act,
+                                 int64_t n_rows, const int64_t *win_start, const int32_t *win_len,
+                                 int64_t n_win, int32_t query_length, float *out, void *stream) {
+  if (!w || !obs || !act || !win_start || !win_len || !out) return fail(IQLHIP_ERR_INVALID, "null argument");
+  if (n_win <= 0 || n_rows <= 0 || query_length < 1) return fail(IQLHIP_ERR_INVALID, "empty problem");
+  if (w->embd_dim != 64) return fail(IQLHIP_ERR_UNSUPPORTED, "embd_dim %d: the kernel is built for 64", w->embd_dim);
+  if (w->num_layers != 1) return fail(IQLHIP_ERR_UNSUPPORTED, "num_layers %d: only 1 is built", w->num_layers);
+  const int nh = w->num_heads;
+  if (nh < 1 || nh > 16 || (nh & (nh - 1))) return fail(IQLHIP_ERR_UNSUPPORTED, "num_heads %d", nh);
+  if (w->inter_dim < 64 || w->inter_dim > 1024 || w->inter_dim % 256)
+    return fail(IQLHIP_ERR_UNSUPPORTED, "inter_dim %d: must be a multiple of 256 up to 1024", w->inter_dim);
+  if (w->state_dim < 1 || w->action_dim < 1 || w->state_dim + w->action_dim > 192)
+    return fail(IQLHIP_ERR_UNSUPPORTED, "state/action dims");
+  if (query_length > w->n_temb) return fail(IQLHIP_ERR_INVALID, "query_length exceeds the timestep table");
+  if (pt_smem_bytes(*w, query_length) > 160 * 1024)
+    return fail(IQLHIP_ERR_UNSUPPORTED, "query_length %d does not fit the 160 KiB LDS", query_length);
+  HIP_TRY(launch_pt(*w, obs, act, n_rows, win_start, win_len, n_win, query_length, out, (hipStream_t)stream));
   return 0;
 }

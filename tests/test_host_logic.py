@@ -1,0 +1,142 @@
+"""CPU tests of the host-side logic of iqlpref_amd (no GPU, no compute calls):
+vectorised dataset preparation vs the oracle loops and the reference goldens,
+config loading, the C-ABI export list."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import relabel_oracle as ro
+from tests import helpers
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(helpers.GOLDEN + "/dataset_ops.npz")
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    from iqlpref_amd import _lib
+    lib = _lib.load()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "iqlhip.h")).read()
+    declared = set(re.findall(r"\b(iqlhip_[a-z0-9_]+)\s*\(", header))
+    declared -= {"iqlhip_status"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libiqlhip.so does not export {name}"
+        assert name in _lib.SYMBOLS, f"_lib.SYMBOLS lacks {name}"
+    assert lib.iqlhip_abi_version() == _lib.ABI_VERSION
+    assert lib.iqlhip_replay_row_stride(29, 8) == 68
+    assert lib.iqlhip_replay_row_stride(17, 6) == 44
+
+
+def test_arena_layout_and_step_cost_match_survey():
+    from iqlpref_amd import _lib
+    lib = _lib.load()
+    c = _lib.TrainerConfig()
+    c.state_dim, c.action_dim, c.hidden_dim, c.batch_size = 29, 8, 256, 256
+    c.precision, c.cosine_t_max, c.dropout_p = 1, 10, -1.0
+    offs = (ctypes.c_int64 * _lib.N_TENSORS)()
+    n_p, n_t = ctypes.c_int64(), ctypes.c_int64()
+    assert lib.iqlhip_arena_layout(ctypes.byref(c), ctypes.byref(offs), ctypes.byref(n_p), ctypes.byref(n_t)) == 0
+    assert n_t.value == 151_554 and n_p.value == 151_554 + 73_729 + 75_536  # parameter counts
+    b, f = ctypes.c_double(), ctypes.c_double()
+    assert lib.iqlhip_step_cost(ctypes.byref(c), ctypes.byref(b), ctypes.byref(f)) == 0
+    assert b.value == 10_908_272
+    c.hidden_dim = 100
+    assert lib.iqlhip_arena_layout(ctypes.byref(c), None, None, None) == _lib.ERR_UNSUPPORTED
+    assert b"hidden_dim" in lib.iqlhip_last_error()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_keep_mask_vectorised_matches_loop(seed):
+    import iqlpref_amd as ia
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(2, 400))
+    term = rng.uniform(size=n) < 0.03
+    tout = rng.uniform(size=n) < 0.05
+    for toe in (False, True):
+        for use_to, M in ((True, 50), (False, int(rng.integers(1, 40)))):
+            want = ro.keep_mask_and_steps(term, tout if use_to else None, M, toe)
+            got = ia.keep_mask_and_steps(term, tout if use_to else None, M, toe)
+            np.testing.assert_array_equal(got[0], want[0], err_msg=f"keep n={n} M={M} toe={toe} to={use_to}")
+            np.testing.assert_array_equal(got[1], want[1], err_msg=f"steps n={n} M={M} toe={toe} to={use_to}")
+
+
+def test_reward_range_and_modify_reward_match_reference(g):
+    import iqlpref_amd as ia
+    rew, term = g["g4/rewards"], g["g4/terminals"]
+    mn, mx, tl = ia.return_reward_range({"rewards": rew.copy(), "terminals": term}, 12)
+    np.testing.assert_allclose([mn, mx], g["g4/range"], rtol=1e-12)
+    np.testing.assert_array_equal(tl, g["g4/trj_lens"])
+    for nr in range(1, 9):
+        ds = {"rewards": rew.copy(), "terminals": term}
+        ia.modify_reward(ds, "antmaze-medium-diverse-v2", nr, max_episode_steps=12)
+        np.testing.assert_allclose(ds["rewards"], g[f"g4/antmaze_nr{nr}"], rtol=1e-6, atol=1e-7)
+    ds = {"rewards": rew.copy(), "terminals": term}
+    ia.modify_reward(ds, "halfcheetah-medium-v2", 1, max_episode_steps=12)
+    np.testing.assert_allclose(ds["rewards"], g["g4/halfcheetah"], rtol=1e-6)
+    ds = {"rewards": rew.copy(), "terminals": term}
+    ia.modify_reward(ds, "pen-human-v1", 1, max_episode_steps=12)
+    np.testing.assert_array_equal(ds["rewards"], g["g4/pen_untouched"])
+    # random cases against the oracle loop
+    rng = np.random.default_rng(3)
+    for _ in range(5):
+        n = int(rng.integers(30, 300))
+        r = rng.standard_normal(n).astype(np.float32)
+        t = rng.uniform(size=n) < 0.04
+        M = int(rng.integers(3, 25))
+        a = ia.return_reward_range({"rewards": r, "terminals": t}, M)
+        b = ro.return_reward_range(r, t, M)
+        np.testing.assert_allclose(a[:2], b[:2], rtol=1e-12)
+        np.testing.assert_array_equal(a[2], b[2])
+
+
+def test_mean_std_and_cvar_helpers(g):
+    import iqlpref_amd as ia
+    m, s = ia.compute_mean_std(g["g4/states"], 1e-3)
+    np.testing.assert_array_equal(m, g["g4/mean"])
+    np.testing.assert_array_equal(s, g["g4/std"])
+    np.testing.assert_array_equal(ia.normalize_states(g["g4/states"], m, s), g["g4/normalized"])
+    preds = g["cvar/preds"]
+    for alpha in (0.0, 0.5, 0.9, 0.95):
+        emp = [ia.empirical_cvar(preds[:, i], alpha) for i in range(preds.shape[1])]
+        np.testing.assert_allclose(emp, g[f"cvar/emp_alpha{alpha}"], rtol=1e-6)
+        np.testing.assert_allclose(ia.cvar_stability_check(preds, alpha, n_checks=20),
+                                   g[f"cvar/stab_alpha{alpha}"], rtol=1e-6)
+    with pytest.raises(ValueError):
+        ia.empirical_cvar(preds[:, 0], -0.1)
+
+
+def test_train_config_schema_and_yaml(tmp_path):
+    import iqlpref_amd as ia
+    c = ia.TrainConfig()
+    assert c.name.startswith("IQL-halfcheetah-medium-expert-v2-") and len(c.name.split("-")[-1]) == 8
+    c2 = ia.TrainConfig(checkpoints_path="/tmp/x", reward_model_root="/r/base", seed=3)
+    assert c2.checkpoints_path == os.path.join("/tmp/x", c2.name)
+    assert c2.reward_model_path == "/r/base_3"  # iql_eval.py:143-146
+    # the reference's own YAML for the headline config (values as written there)
+    y = tmp_path / "c.yaml"
+    y.write_text("actor_lr: 3e-4\nbatch_size: 256\nbeta: 10.0\nbuffer_size: 10000000\n"
+                 "checkpoints_path: null\ndevice: cuda\ndiscount: 0.99\nenv: antmaze-medium-diverse-v2\n"
+                 "eval_freq: 5000\ngroup: g\niql_deterministic: false\niql_tau: 0.9\nload_model: ''\n"
+                 "max_timesteps: 1000000\nn_episodes: 100\nname: IQL\nnormalize: true\n"
+                 "normalize_reward: 1\nqf_lr: 3e-4\nproject: IQL-pref\nseed: 0\ntau: 0.005\nvf_lr: 3e-4\n")
+    c3 = ia.load_config(str(y), seed=5)
+    assert c3.actor_lr == 3e-4 and c3.beta == 10.0 and c3.normalize_reward == 1 and c3.seed == 5
+    assert c3.buffer_size == 10_000_000 and c3.iql_deterministic is False and c3.checkpoints_path is None
+    with pytest.raises(ValueError):
+        ia.load_config(None, not_a_field=1)
+    # pen YAML writes `normalize_reward: false` for an int field
+    assert ia.load_config(None, normalize_reward=False).normalize_reward == 0
+
+
+def test_no_cpu_path():
+    import iqlpref_amd as ia
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ia.ReplayBuffer(3, 2, 10, "cpu")
