@@ -1,0 +1,62 @@
+"""Multi-GPU execution model: one process per GPU, one independent (seed, dataset)
+run per rank -- what the reference does with one W&B agent per GPU
+(ensemble_sweeps/launch.sh:84-94).  No parameter or gradient ever crosses ranks;
+the only collective is the all-gather of a fixed-size metric record at log / eval
+time (RCCL over xGMI under ``backend="nccl"``, gloo in CPU tests).
+"""
+import os
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+# fixed layout of the per-rank record (float64): latency-bound, 9 x 8 bytes
+FIELDS = ("seed", "total_it", "value_loss", "q_loss", "actor_loss", "mean_score",
+          "avg_steps_to_goal", "steps_per_sec", "rank")
+
+
+def init_from_env(backend: Optional[str] = None, device: Optional[str] = None) -> int:
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
+    Returns the rank; a no-op (rank 0) when WORLD_SIZE is 1 or unset."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or dist.is_initialized():
+        return dist.get_rank() if dist.is_initialized() else 0
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = torch.device(device)
+    dist.init_process_group(backend, **kw)
+    return dist.get_rank()
+
+
+def rank_seed(base_seed: int) -> int:
+    """Seed of this rank's run: base + rank (tr_sweeps/*.yaml grid their seeds)."""
+    return base_seed + (dist.get_rank() if dist.is_initialized() else 0)
+
+
+def gather_metrics(record: Dict[str, float], device: Optional[str] = None) -> List[Dict[str, float]]:
+    """All-gather one metric record per rank; every rank receives the full list."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    vals = [float(record.get(k, float("nan"))) for k in FIELDS[:-1]] + [float(rank)]
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [dict(zip(FIELDS, vals))]
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    t = torch.tensor(vals, dtype=torch.float64, device=dev)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [dict(zip(FIELDS, o.tolist())) for o in out]
+
+
+def summarize(records: List[Dict[str, float]]) -> Dict[str, float]:
+    """Across-seed mean / std of the scores, total throughput (rank 0 logs this)."""
+    import math
+    scores = [r["mean_score"] for r in records if not math.isnan(r["mean_score"])]
+    out = {"n_seeds": float(len(records)),
+           "steps_per_sec_total": sum(r["steps_per_sec"] for r in records
+                                      if not math.isnan(r["steps_per_sec"]))}
+    if scores:
+        m = sum(scores) / len(scores)
+        out["mean_score_mean"] = m
+        out["mean_score_std"] = (sum((s - m) ** 2 for s in scores) / len(scores)) ** 0.5
+    return out

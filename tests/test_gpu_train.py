@@ -1,0 +1,112 @@
+"""End-to-end: train(config) on synthetic data (the reference's loop, ref:1393-1570)
+checked against the oracle driven with the same seeds, plus the relabel branches of
+build_dataset.  -m gpu."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import iql_oracle as orc
+from oracle import philox
+from oracle import relabel_oracle as ro
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def synth(n, S, A, seed=0):
+    rng = np.random.default_rng(seed)
+    return {
+        "observations": (rng.standard_normal((n, S)) * 2 + 0.5).astype(np.float32),
+        "actions": rng.uniform(-1, 1, (n, A)).astype(np.float32),
+        "rewards": (rng.uniform(size=n) < 0.05).astype(np.float32),
+        "next_observations": (rng.standard_normal((n, S)) * 2 + 0.5).astype(np.float32),
+        "terminals": (rng.uniform(size=n) < 0.01).astype(np.float32),
+    }
+
+
+def test_train_loop_matches_oracle(tmp_path):
+    import iqlpref_amd as ia
+    S, A, N, B = 29, 8, 3000, 64
+    data = synth(N, S, A)
+    cfg = ia.TrainConfig(env="antmaze-medium-diverse-v2", max_timesteps=40, log_freq=10, eval_freq=20,
+                         batch_size=B, normalize_reward=1, beta=10.0, iql_tau=0.9, seed=5, device=DEV,
+                         buffer_size=10_000_000, checkpoints_path=str(tmp_path))
+    logs = []
+    tr = ia.train(cfg, dataset={k: v.copy() for k, v in data.items()}, state_dim=S, action_dim=A,
+                  max_action=1.0, logger=lambda d, step: logs.append((step, d)),
+                  evaluate=lambda actor, t: (np.array([1.0, 0.0]), [17]), precision="fp32")
+    assert tr.total_it == 40
+    loss_logs = [d for _, d in logs if "value_loss" in d]
+    eval_logs = [d for _, d in logs if "mean_score" in d]
+    assert len(loss_logs) == 4 and len(eval_logs) == 2
+    assert eval_logs[0] == {"mean_score": 0.5, "avg_steps_to_goal": 17.0}
+    for step in (19, 39):  # ref:1561 names the file after the 0-based step
+        ck = torch.load(os.path.join(cfg.checkpoints_path, f"checkpoint_{step}.pt"), weights_only=True)
+        assert sorted(ck) == ["actor", "actor_lr_schedule", "actor_optimizer", "q_optimizer", "qf",
+                              "total_it", "v_optimizer", "vf"]
+    # ---- the same run in the oracle: dataset prep (ref:1435-1448), init (ref:1467-1480), 10 steps ----
+    d = {k: v.copy() for k, v in data.items()}
+    d["rewards"] -= 1.0
+    mean, std = d["observations"].mean(0), d["observations"].std(0) + 1e-3
+    d["observations"] = (d["observations"] - mean) / std
+    d["next_observations"] = (d["next_observations"] - mean) / std
+    ia.set_seed(5)
+    q, v, a = ia.TwinQ(S, A), ia.ValueFunction(S), ia.GaussianPolicy(S, A, 1.0)
+    sd = lambda m: {k: t.detach().numpy() for k, t in m.state_dict().items()}
+    o = orc.IQLOracle(sd(q), sd(v), sd(a), iql_tau=0.9, beta=10.0, max_steps=40, discount=0.99, tau=0.005,
+                      mode="fp32")
+    acc = np.zeros(3)
+    for t in range(10):
+        out = o.train(orc.gather_batch(d, philox.sample_indices(5, t, B, N)))
+        acc += [out["value_loss"], out["q_loss"], out["actor_loss"]]
+    got = loss_logs[0]
+    np.testing.assert_allclose([got["value_loss"], got["q_loss"], got["actor_loss"]], acc / 10, rtol=5e-5)
+
+
+def test_build_dataset_branches(tmp_path):
+    """Config-driven relabel selection (ref:1402-1429) for the MR and PT models."""
+    import iqlpref_amd as ia
+    S, A, N = 6, 3, 400
+    rng = np.random.default_rng(1)
+    raw = {"observations": rng.standard_normal((N, S)).astype(np.float32),
+           "actions": rng.uniform(-1, 1, (N, A)).astype(np.float32),
+           "rewards": np.zeros(N, np.float32), "terminals": rng.uniform(size=N) < 0.02,
+           "timeouts": np.zeros(N, bool)}
+    raw["timeouts"][[99, 199, 299]] = True
+
+    class Env:
+        _max_episode_steps = 100
+
+    # MR model directory written the way the reference's trainer would
+    mr = tmp_path / "mr"
+    mr.mkdir()
+    (mr / "config.yaml").write_text("activations: tanh\n")
+    w = [rng.standard_normal(s).astype(np.float32) * 0.4 for s in ((S + A, 16), (16,), (16, 16), (16,), (16, 1), (1,))]
+    torch.save({"net": {"_orig_mod.layers.0.W": torch.from_numpy(w[0]), "_orig_mod.layers.0.b": torch.from_numpy(w[1]),
+                        "_orig_mod.layers.linear_1.W": torch.from_numpy(w[2]),
+                        "_orig_mod.layers.linear_1.b": torch.from_numpy(w[3]),
+                        "_orig_mod.output.W": torch.from_numpy(w[4]), "_orig_mod.output.b": torch.from_numpy(w[5])}},
+               mr / "best_model.pt")
+    cfg = ia.TrainConfig(env="pen-human-v1", reward_model_path=str(mr), query_length=1, device=DEV)
+    out = ia.build_dataset(cfg, Env(), dict(raw))
+    want = ro.qlearning_dataset_mr(dict(raw), w, 100, activation="tanh")
+    for k in want:
+        np.testing.assert_allclose(np.asarray(out[k], np.float32), np.asarray(want[k], np.float32),
+                                   rtol=2e-5, atol=2e-5)
+
+    # PT model directory
+    ptd = tmp_path / "pt"
+    ptd.mkdir()
+    (ptd / "config.yaml").write_text("num_heads: 4\nintermediate_dim: 256\nmodel_eps: 1.0e-5\n")
+    p = ro.make_pt_params(rng, S, A, 100, embd=64, pref=16, inter=256, layers=1)
+    state = {k: torch.from_numpy(v) for k, v in p.items()}
+    state["gpt.layers.0.attention.causal_bias"] = torch.tril(torch.ones(1, 1, 32, 32))
+    torch.save({"net": state}, ptd / "best_model.pt")
+    cfg = ia.TrainConfig(env="pen-human-v1", reward_model_path=str(ptd), query_length=10, device=DEV)
+    out = ia.build_dataset(cfg, Env(), dict(raw))
+    want = ro.qlearning_dataset_pt(dict(raw), p, 100, 10, num_heads=4)
+    for k in want:
+        np.testing.assert_allclose(np.asarray(out[k], np.float32), np.asarray(want[k], np.float32),
+                                   rtol=5e-3, atol=5e-3)
