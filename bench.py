@@ -173,6 +173,17 @@ def main():
         nl = C.c_int64()
         _lib.check(lib.iqlhip_trainer_get_timing(tr._handle, C.byref(avg), C.byref(nl)))
         _lib.check(lib.iqlhip_trainer_set_timing(tr._handle, 0))
+        # algorithmic bytes: the gather term belongs to k_forward, every
+        # parameter / moment / target byte is moved by k_update -- the dominant kernel
+        gather_bytes = 4.0 * BATCH * (2 * S_DIM + A_DIM + 2)
+        upd_bytes = bytes_step.value - gather_bytes
+        upd_us = avg[2] * 1e3
+        achieved = upd_bytes / (upd_us * 1e-6) / 1e9  # GB/s of k_update, HIP events on the launch stream
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_b_traffic.json")
+        if os.path.exists(tpath):  # PMC pass (separate rocprofv3 --pmc runs), bytes per launch of k_update
+            with open(tpath) as f:
+                traffic = json.load(f).get("k_update_bytes_per_launch")
         out = {
             "metric": "iql_grad_steps_per_sec", "value": steps_per_s, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -183,14 +194,18 @@ def main():
                                    "1M-transition device replay, batch 256, one seed per GPU",
                        "batch": BATCH, "buffer_rows": N_ROWS, "graph_unroll": args.unroll},
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "bytes_per_step": bytes_step.value, "device_us_per_step": step_us_dev,
-                "kernel_us": {"k_forward": avg[0] * 1e3, "k_backward": avg[1] * 1e3,
-                              "k_update": avg[2] * 1e3},
-                "mfma_tflops": flops_step.value / (step_us_dev * 1e-6) / 1e12,
-                "mfma_peak_tflops": MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16"
-                else MFMA_F32_PEAK_TFLOPS,
+                "kernel": "k_update", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": upd_bytes, "launch_us": upd_us,
+                "launches_timed": int(nl.value),
+                "step": {"bytes_per_step": bytes_step.value, "device_us_per_step": step_us_dev,
+                         "achieved_gbs": bytes_step.value / (step_us_dev * 1e-6) / 1e9,
+                         "frac": bytes_step.value / (step_us_dev * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "kernel_us": {"k_forward": avg[0] * 1e3, "k_backward": avg[1] * 1e3,
+                                       "k_update": avg[2] * 1e3},
+                         "mfma_tflops": flops_step.value / (step_us_dev * 1e-6) / 1e12,
+                         "mfma_peak_tflops": MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16"
+                         else MFMA_F32_PEAK_TFLOPS},
             },
         }
         if not args.no_cpu_baseline:

@@ -148,7 +148,7 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
         with open(os.path.join(config.checkpoints_path, "config.yaml"), "w") as f:
             yaml.safe_dump(asdict(config), f)
 
-    seed = config.seed
+    seed = D.rank_seed(config.seed)  # one independent seed per rank / GPU
     set_seed(seed, None)
     q_network = TwinQ(state_dim, action_dim).to(config.device)
     v_network = ValueFunction(state_dim).to(config.device)
