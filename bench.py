@@ -105,11 +105,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (there is no CPU path)")
+    # rehearsal knob (1-GPU box): IQL_BENCH_BACKEND=gloo puts every rank on cuda:0 and runs the
+    # collectives over gloo; the driver's multi-GPU runs use the default (one GPU per rank, RCCL)
+    backend = os.environ.get("IQL_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
+    cdev = device if backend == "nccl" else "cpu"  # where collective payloads live
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device(device))
+        kw = {"device_id": torch.device(device)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     import iqlpref_amd as ia
     from iqlpref_amd import _lib
@@ -150,10 +156,10 @@ def main():
         raise SystemExit(f"non-finite losses after the timed region: {last}")
 
     # max over ranks of the wall time
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        rec = torch.tensor([seed, tr.total_it, *last.tolist()], dtype=torch.float64, device=device)
+        rec = torch.tensor([seed, tr.total_it, *last.tolist()], dtype=torch.float64, device=cdev)
         recs = [torch.zeros_like(rec) for _ in range(world)]
         dist.all_gather(recs, rec)  # RCCL: the path's only collective (metric record)
     dt_max = float(tmax.item())

@@ -236,7 +236,8 @@ int iqlhip_step_cost(const iqlhip_trainer_config *cfg, double *bytes, double *fl
  * made with timing enabled (bench.py roofline leg).  enable != 0 brackets
  * every launch of the dominant kernel with events on `stream`.              */
 int iqlhip_trainer_set_timing(iqlhip_trainer *t, int32_t enable);
-/* avg_ms[3] = mean duration of the forward / backward / update kernels.     */
+/* avg_ms[3] = mean duration of the forward / backward / update kernels, with
+ * the cost of an empty event pair (measured in the same pass) subtracted.    */
 int iqlhip_trainer_get_timing(iqlhip_trainer *t, double avg_ms[3], int64_t *n_launches);
 
 #ifdef __cplusplus

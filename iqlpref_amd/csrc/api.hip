@@ -110,8 +110,9 @@ struct iqlhip_trainer {
   hipStream_t cap_stream = nullptr;  // capture only (the legacy default stream cannot capture)
   // timing
   bool timing = false;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double t_acc[3] = {0, 0, 0};
+  double t_empty = 0;  // interval of two back-to-back event records (event overhead)
   int64_t t_n = 0;
 };
 
@@ -461,6 +462,7 @@ extern "C" int iqlhip_trainer_set_timing(iqlhip_trainer *t, int32_t enable) {
   if (!t) return fail(IQLHIP_ERR_INVALID, "null trainer");
   t->timing = enable != 0;
   t->t_acc[0] = t->t_acc[1] = t->t_acc[2] = 0;
+  t->t_empty = 0;
   t->t_n = 0;
   if (t->timing)
     for (auto &e : t->ev)
@@ -470,7 +472,11 @@ extern "C" int iqlhip_trainer_set_timing(iqlhip_trainer *t, int32_t enable) {
 
 extern "C" int iqlhip_trainer_get_timing(iqlhip_trainer *t, double avg_ms[3], int64_t *n) {
   if (!t) return fail(IQLHIP_ERR_INVALID, "null trainer");
-  for (int k = 0; k < 3; ++k) avg_ms[k] = t->t_n ? t->t_acc[k] / (double)t->t_n : 0.0;
+  // event-pair overhead (measured on an empty interval in the same pass) is subtracted
+  for (int k = 0; k < 3; ++k) {
+    const double v = t->t_n ? (t->t_acc[k] - t->t_empty) / (double)t->t_n : 0.0;
+    avg_ms[k] = v > 0 ? v : 0.0;
+  }
   if (n) *n = t->t_n;
   return 0;
 }
@@ -496,12 +502,16 @@ static int run_steps(iqlhip_trainer *t, const DevArgs &args, int64_t n_steps, in
       HIP_TRY(hipEventRecord(t->ev[2], st));
       HIP_TRY(launch_update(t->bf16, t->ddesc, t->dargs, t->dctr, t->ditems, t->n_items, st));
       HIP_TRY(hipEventRecord(t->ev[3], st));
-      HIP_TRY(hipEventSynchronize(t->ev[3]));
+      HIP_TRY(hipEventRecord(t->ev[4], st));  // empty interval: what a record pair costs by itself
+      HIP_TRY(hipEventSynchronize(t->ev[4]));
       for (int k = 0; k < 3; ++k) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, t->ev[k], t->ev[k + 1]));
         t->t_acc[k] += ms;
       }
+      float ems = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ems, t->ev[3], t->ev[4]));
+      t->t_empty += ems;
       t->t_n++;
     }
     return 0;

@@ -250,3 +250,42 @@ def test_errors(gh):
         tr.train(b)
     with pytest.raises(RuntimeError):
         ia.ReplayBuffer(3, 2, 10, "cpu")  # no CPU path
+
+
+@pytest.mark.parametrize("S,A,H,B,det,drop", [(29, 8, 256, 1024, False, None), (45, 24, 256, 256, False, 0.1),
+                                              (17, 6, 128, 48, True, None), (11, 3, 64, 16, False, None)])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_shapes_beyond_the_goldens_vs_oracle(gh, S, A, H, B, det, drop, mode):
+    """BASELINE configs 3/5 shapes and odd sizes: HIP vs the (reference-pinned) oracle."""
+    import iqlpref_amd as ia
+    rng = np.random.default_rng(B)
+    N = 2000
+    data = {"observations": rng.standard_normal((N, S)).astype(np.float32),
+            "actions": rng.uniform(-1, 1, (N, A)).astype(np.float32),
+            "rewards": rng.standard_normal(N).astype(np.float32),
+            "next_observations": rng.standard_normal((N, S)).astype(np.float32),
+            "terminals": (rng.uniform(size=N) < 0.05).astype(np.float32)}
+    torch.manual_seed(B)
+    q, v = ia.TwinQ(S, A, hidden_dim=H), ia.ValueFunction(S, hidden_dim=H)
+    actor = (ia.DeterministicPolicy if det else ia.GaussianPolicy)(S, A, 1.0, hidden_dim=H, dropout=drop)
+    sd = lambda m: {k: t.detach().numpy().copy() for k, t in m.state_dict().items()}
+    hyper = dict(s_dim=S, a_dim=A, hidden=H, deterministic=det, dropout=drop, iql_tau=0.8, beta=3.0,
+                 max_steps=1000, discount=0.99, tau=0.005, n_rows=N)
+    nets = (sd(q), sd(v), sd(actor))
+    tr = gh.make_trainer(hyper, nets, mode, seed=7)
+    buf = gh.make_buffer(hyper, data)
+    K = 3
+    got = tr.train_steps(buf, K, B).cpu().numpy()
+    o = helpers.make_oracle(hyper, nets, mode)
+    for t in range(K):
+        km = None
+        if drop:
+            km = [philox.dropout_keep(7, t, 1, B, H, drop), philox.dropout_keep(7, t, 2, B, H, drop)]
+        out = o.train(orc.gather_batch(data, philox.sample_indices(7, t, B, N)), km)
+        np.testing.assert_allclose(got[t], [out["value_loss"], out["q_loss"], out["actor_loss"]],
+                                   rtol=3e-5 if mode == "fp32" else 6e-3)
+    for name, mod, opar in (("qf", tr.qf, o.qf), ("actor", tr.actor, o.actor), ("q_target", tr.q_target, o.q_target)):
+        for k, t in mod.state_dict().items():
+            # 3 sign-like Adam steps: a gradient element near zero amplifies fp32 summation-order noise
+            np.testing.assert_allclose(t.cpu().numpy(), opar[k], atol=5e-6 if mode == "fp32" else 2e-3, rtol=0,
+                                       err_msg=f"{name}/{k}")

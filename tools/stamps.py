@@ -73,3 +73,15 @@ w = d[2, :, :, 0]
 used = np.where(w[:, 0] > 0)[0]
 mb = used.max()
 print(f"k_update misc block {mb}: start +{(w[mb,0]-w[used,0].min())*10:.0f} ns, duration {(w[mb,4]-w[mb,0])*10:.0f} ns")
+
+if "--hist" in sys.argv:
+    w = d[2, :, :, 0]
+    used = np.where((w[:, 0] > 0) & (w[:, 4] > 0))[0]
+    t0 = w[used, 0].min()
+    dur = (w[used, 4] - w[used, 0]) * 10
+    end = (w[used, 4] - t0) * 10
+    order = np.argsort(end)
+    print("k_update blocks by finish time (block, xcd, start, s0->1, s1->3, s3->4, end):")
+    for b in used[order][-24:]:
+        s = [(w[b, k] - t0) * 10 if w[b, k] > 0 else -1 for k in range(5)]
+        print(f"  {b:3d} x{b%8} start {s[0]:6.0f}  {s[1]-s[0]:6.0f} {s[3]-s[1]:6.0f} {s[4]-s[3]:6.0f}  end {s[4]:6.0f}")
