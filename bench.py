@@ -93,6 +93,10 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--unroll", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--agents-per-gpu", type=int, default=4,
+                    help="extra leg (N=1 only): aggregate steps/s of this many independent seeds sharing "
+                         "the GPU on separate streams -- the reference launcher's AGENTS_PER_GPU "
+                         "(ensemble_sweeps/launch.sh:12); 0 disables.  `value` is always 1 seed per GPU")
     args = ap.parse_args()
 
     import torch
@@ -214,6 +218,30 @@ def main():
                          else MFMA_F32_PEAK_TFLOPS},
             },
         }
+        if world == 1 and args.agents_per_gpu > 1:
+            # independent seeds on independent streams; same dataset (a sweep varies the seed only)
+            A_ = args.agents_per_gpu
+            trs = [tr] + [build_trainer(ia, torch, device, seed + 100 + i, args.precision) for i in range(1, A_)]
+            streams = [torch.cuda.Stream() for _ in range(A_)]
+            def run_multi(n):
+                done = 0
+                while done < n:
+                    c = min(n - done, 2_000)
+                    for t_, st_ in zip(trs, streams):
+                        with torch.cuda.stream(st_):
+                            t_.train_steps(buf, c, BATCH, return_losses=False, graph_unroll=args.unroll)
+                    done += c
+            torch.cuda.synchronize()
+            run_multi(2_000)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_multi = 20_000
+            run_multi(n_multi)
+            torch.cuda.synchronize()
+            dt_m = time.perf_counter() - t1
+            out["agents_per_gpu"] = {"agents": A_, "value": A_ * n_multi / dt_m, "unit": "steps/s",
+                                     "steps_per_agent": n_multi,
+                                     "note": "aggregate of independent seeds sharing one GPU; not `value`"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data)
         print(json.dumps(out), flush=True)

@@ -406,12 +406,20 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
   using K = KCfg<BF16, H>;
   using P = Prec<BF16>;
   using T = typename P::T;
-  // XCD slot x = blockIdx & 7 serves network x/2: each network's slabs sit on two XCDs
+  // XCD slot x = blockIdx & 7 serves network x/2: each network's slabs sit on two XCDs.
+  // At H >= 128 two work-groups share a (net, slab): each streams HALF of W2^T (the per-CU
+  // fetch rate is what bounds this kernel) and produces half of the dZ1 columns; both redo
+  // the cheap loss / dZ2 phase, work-group 0 stores it.
+  constexpr int SPLIT = K::TPW >= 2 ? 2 : 1;
+  constexpr int TPH = K::TPW / SPLIT;  // n-tiles per wave in the dZ1 GEMM
   const int xcd = blockIdx.x & 7, net = xcd >> 1;
-  const int slab = ((blockIdx.x >> 3) << 1) | (xcd & 1);
+  const int rest = blockIdx.x >> 3;
+  const int half = rest % SPLIT;
+  const int slab = ((rest / SPLIT) << 1) | (xcd & 1);
   const TrainerDesc &D = *Dp;
   const int nslab = D.B / SLAB;
   if (slab >= nslab) return;
+  const int tile0 = half * (H / 16 / SPLIT) + (threadIdx.x >> 6) * TPH;
   const TrainNet N = D.net[net];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -430,13 +438,13 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
   STAMP(1, 0);
 
   // ---- request everything that does not depend on the loss ----
-  uint4 w2t[K::NKC][TPW];
-  load_w<P, K::NKC, TPW>(w2t, reinterpret_cast<const T *>(N.w2ct), K::NK2, 0, K::NKC, wave * TPW, lane);
-  float h1v[TPW][4];
+  uint4 w2t[K::NKC][TPH];
+  load_w<P, K::NKC, TPH>(w2t, reinterpret_cast<const T *>(N.w2ct), K::NK2, 0, K::NKC, tile0, lane);
+  float h1v[TPH][4];
 #pragma unroll
-  for (int jj = 0; jj < TPW; ++jj)
+  for (int jj = 0; jj < TPH; ++jj)
     load4T<BF16>(reinterpret_cast<const T *>(D.hT) + (size_t)(net * 2 + 0) * H * BP +
-                     fidx<P>(16 * (wave * TPW + jj) + r, slab * SLAB + 4 * q, nkb),
+                     fidx<P>(16 * (tile0 + jj) + r, slab * SLAB + 4 * q, nkb),
                  h1v[jj]);
   const int c2 = tid;  // hidden unit this thread owns in the dZ2 phase
   float h2v[16], w3v[32];
@@ -516,7 +524,7 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
     for (int j = 0; j < N.out_dim; ++j) s += lterm[tid * 32 + j];
     rowsum[tid] = s;
   }
-  if (net == NET_A && !D.deterministic && tid >= 64 && tid < 64 + D.A) {
+  if (half == 0 && net == NET_A && !D.deterministic && tid >= 64 && tid < 64 + D.A) {
     const int j = tid - 64;
     float s = 0.f;
 #pragma unroll
@@ -524,7 +532,7 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
     stg(D.lsp + (size_t)slab * D.A + j, s);
   }
   // d(out), feature-major, for the layer-3 weight gradient
-  for (int e = tid; e < N.out_dim * SLAB; e += 256) {
+  for (int e = tid; half == 0 && e < N.out_dim * SLAB; e += 256) {
     const int j = e / SLAB, rr = e - j * SLAB;
     stg(reinterpret_cast<T *>(D.dz3T) + (size_t)net * D.opmax * BP + fidx<P>(j, slab * SLAB + rr, nkb),
         P::from_f32(dz3[rr * 32 + j]));
@@ -554,12 +562,12 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
         outv[i] = h2v[rr] > 0.f ? sv : 0.f;
         dz2s[rr * HP + c2] = P::from_f32(outv[i]);
       }
-      store4T<BF16>(dst + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), outv);
+      if (half == 0) store4T<BF16>(dst + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), outv);
     }
   }
   __syncthreads();
   STAMP(1, 3);
-  if (tid == 0) {
+  if (tid == 0 && half == 0) {
     float s = 0.f;
 #pragma unroll
     for (int rr = 0; rr < SLAB; ++rr) s += rowsum[rr];
@@ -568,19 +576,19 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
 
   // ---- dZ1 = (dZ2 W2) * relu'(h1)   (MFMA, B operand = transposed copy) ----
   {
-    f32x4 acc[TPW];
+    f32x4 acc[TPH];
 #pragma unroll
-    for (int jj = 0; jj < TPW; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mma_w<P, K::NKC, TPW>(dz2s, HP, 0, K::NKC, w2t, acc, lane);
+    for (int jj = 0; jj < TPH; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma_w<P, K::NKC, TPH>(dz2s, HP, 0, K::NKC, w2t, acc, lane);
 #pragma unroll 1
     for (int ch = 1; ch < K::NCH; ++ch) {
-      load_w<P, K::NKC, TPW>(w2t, reinterpret_cast<const T *>(N.w2ct), K::NK2, ch * K::NKC, K::NKC,
-                             wave * TPW, lane);
-      mma_w<P, K::NKC, TPW>(dz2s, HP, ch * K::NKC * P::KM, K::NKC, w2t, acc, lane);
+      load_w<P, K::NKC, TPH>(w2t, reinterpret_cast<const T *>(N.w2ct), K::NK2, ch * K::NKC, K::NKC,
+                             tile0, lane);
+      mma_w<P, K::NKC, TPH>(dz2s, HP, ch * K::NKC * P::KM, K::NKC, w2t, acc, lane);
     }
 #pragma unroll
-    for (int jj = 0; jj < TPW; ++jj) {
-      const int col = 16 * (wave * TPW + jj) + r;
+    for (int jj = 0; jj < TPH; ++jj) {
+      const int col = 16 * (tile0 + jj) + r;
       float outv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -981,7 +989,7 @@ hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD
 }
 hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
                            DevCtr *c, hipStream_t st) {
-  const int grid = 8 * ((D.B / SLAB + 1) / 2);
+  const int grid = 8 * ((D.B / SLAB + 1) / 2) * (D.H >= 128 ? 2 : 1);
   const size_t sm = bwd_smem_bytes(bf16, D.H);
 #define CALL(BF, HH) hipLaunchKernelGGL((k_backward<BF, HH>), dim3(grid), dim3(256), sm, st, dD, a, c)
   DISPATCH_H(bf16, D.H, CALL);

@@ -286,6 +286,10 @@ def test_shapes_beyond_the_goldens_vs_oracle(gh, S, A, H, B, det, drop, mode):
                                    rtol=3e-5 if mode == "fp32" else 6e-3)
     for name, mod, opar in (("qf", tr.qf, o.qf), ("actor", tr.actor, o.actor), ("q_target", tr.q_target, o.q_target)):
         for k, t in mod.state_dict().items():
-            # 3 sign-like Adam steps: a gradient element near zero amplifies fp32 summation-order noise
-            np.testing.assert_allclose(t.cpu().numpy(), opar[k], atol=5e-6 if mode == "fp32" else 2e-3, rtol=0,
-                                       err_msg=f"{name}/{k}")
+            # Adam's first steps are sign-like (update = lr * g / (|g| + eps)): an element whose
+            # gradient is ~eps-sized turns fp32 summation-order noise into an O(lr) difference.
+            # Bound the bulk tightly and the (rare) outliers by K * lr.
+            diff = np.abs(t.cpu().numpy() - opar[k])
+            tol = 2e-6 if mode == "fp32" else 2e-3
+            assert (diff > tol).mean() < 1e-4, f"{name}/{k}: {(diff > tol).mean():.2e} of elements off"
+            assert diff.max() < K * 3e-4 + tol, f"{name}/{k}: max {diff.max():.3e}"
