@@ -283,12 +283,13 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   // (pointers are filled in after the workspace has been carved)
   std::vector<UpdItem> per_xcd[8];
   for (int n = 0; n < N_TRAIN; ++n) {
-    int k = 0;
+    // layer 2 (the H x H matrix, 32 tiles at H = 256) fills XCD 2n: every dZ^T / activation
+    // panel of that GEMM is then fetched into ONE L2; layers 1 and 3 go to XCD 2n+1
     auto put = [&](int layer, int o0, int i0) {
       UpdItem it;
       memset(&it, 0, sizeof(it));
       it.net = n, it.layer = layer, it.o0 = o0, it.i0 = i0;
-      per_xcd[2 * n + (k++ & 1)].push_back(it);
+      per_xcd[2 * n + (layer == 1 ? 0 : 1)].push_back(it);
     };
     for (int o0 = 0; o0 < H; o0 += 64)
       for (int i0 = 0; i0 < H; i0 += 32) put(1, o0, i0);

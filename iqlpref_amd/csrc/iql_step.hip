@@ -414,8 +414,10 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
   constexpr int TPH = K::TPW / SPLIT;  // n-tiles per wave in the dZ1 GEMM
   const int xcd = blockIdx.x & 7, net = xcd >> 1;
   const int rest = blockIdx.x >> 3;
-  const int half = rest % SPLIT;
-  const int slab = ((rest / SPLIT) << 1) | (xcd & 1);
+  // SPLIT == 2: XCD 2n runs half 0 of every slab of net n, XCD 2n+1 half 1, so each L2
+  // fetches only the half of W2^T its work-groups stream
+  const int half = SPLIT == 2 ? (xcd & 1) : 0;
+  const int slab = SPLIT == 2 ? rest : ((rest << 1) | (xcd & 1));
   const TrainerDesc &D = *Dp;
   const int nslab = D.B / SLAB;
   if (slab >= nslab) return;
@@ -989,7 +991,7 @@ hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD
 }
 hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
                            DevCtr *c, hipStream_t st) {
-  const int grid = 8 * ((D.B / SLAB + 1) / 2) * (D.H >= 128 ? 2 : 1);
+  const int grid = 8 * (D.H >= 128 ? D.B / SLAB : (D.B / SLAB + 1) / 2);
   const size_t sm = bwd_smem_bytes(bf16, D.H);
 #define CALL(BF, HH) hipLaunchKernelGGL((k_backward<BF, HH>), dim3(grid), dim3(256), sm, st, dD, a, c)
   DISPATCH_H(bf16, D.H, CALL);
