@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -23,6 +24,7 @@ hipError_t launch_backward(bool, const TrainerDesc &, const TrainerDesc *, const
 hipError_t launch_update(bool, const TrainerDesc *, const DevArgs *, DevCtr *, const UpdItem *, int,
                          hipStream_t);
 hipError_t launch_sync_weights(bool, const TrainerDesc *, hipStream_t);
+
 hipError_t launch_infer(bool, const TrainerDesc &, const TrainerDesc *, const FwdNet &, const float *,
                         const float *, int64_t, float *, int, hipStream_t);
 
@@ -101,6 +103,7 @@ struct iqlhip_trainer {
   DevCtr *dctr = nullptr;
   UpdItem *ditems = nullptr;
   int n_items = 0;
+
   float *batch_rows = nullptr;  // [B][stride] staging for iqlhip_train_batch
   int64_t total_it = 0;
   double lr_q, lr_v, lr_a_base;
@@ -244,7 +247,6 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   D.opmax = round_up(A, 16);
   D.xrows = round_up(S + A, 64);
   D.k1max = round_up(S + A, KM);
-
   // ---- workspace ----
   size_t total = 0;
   auto add = [&](size_t bytes) { total += (bytes + 255) / 256 * 256; };
@@ -271,6 +273,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   add((size_t)B * D.OUTW * 4);
   add((size_t)4 * (B / 16) * 4);
   add((size_t)(B / 16) * A * 4);
+  add((size_t)A * 4);
   const int stride = iqlhip_replay_row_stride(S, A);
   add((size_t)B * stride * 4);
   add(sizeof(DevArgs));
@@ -352,11 +355,13 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   D.outs = carve<float>(p, (size_t)B * D.OUTW);
   D.lossp = carve<float>(p, (size_t)4 * (B / 16));
   D.lsp = carve<float>(p, (size_t)(B / 16) * A);
+  D.ls_snap = carve<float>(p, (size_t)A);
   t->batch_rows = carve<float>(p, (size_t)B * stride);
   t->dargs = carve<DevArgs>(p, 1);
   t->dctr = carve<DevCtr>(p, 1);
   t->ddesc = carve<TrainerDesc>(p, 1);
   t->ditems = carve<UpdItem>(p, items.size());
+
   for (auto &it : items) {
     if (it.net < 0) continue;
     const TrainNet &N = D.net[it.net];
@@ -368,6 +373,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
     it.has_target = N.has_target;
     it.group = it.net == NET_V ? 1 : (it.net == NET_A ? 2 : 0);
     it.off_w = N.off_w[L], it.off_b = N.off_b[L], it.toff_w = N.toff_w[L], it.toff_b = N.toff_b[L];
+
     it.wc = N.wc[L], it.tc = N.has_target ? N.tc[L] : nullptr, it.w2ct = (L == 1) ? N.w2ct : nullptr;
     const size_t plane = (size_t)H * D.BP * es;
     it.Xsrc = (L == 0) ? D.xT : reinterpret_cast<char *>(D.hT) + (size_t)(it.net * 2 + (L - 1)) * plane;
@@ -419,6 +425,7 @@ extern "C" int iqlhip_trainer_destroy(iqlhip_trainer *t) {
   if (!t) return 0;
   if (t->gexec) (void)hipGraphExecDestroy(t->gexec);
   if (t->cap_stream) (void)hipStreamDestroy(t->cap_stream);
+
   for (auto &e : t->ev)
     if (e) (void)hipEventDestroy(e);
   if (t->ws) (void)hipFree(t->ws);

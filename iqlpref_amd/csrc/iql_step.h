@@ -60,6 +60,7 @@ struct TrainerDesc {
   float *outs;    // [B][OUTW]
   float *lossp;   // [4][nslab]   per-slab loss partial sums
   float *lsp;     // [nslab][A]   per-slab d(loss)/d(std) partial sums
+  float *ls_snap; // [A] log_std as of the start of the step (written by k_forward's spare block)
   int32_t opmax, xrows;
   unsigned long long *dbg;  // diagnostic stamps (IQL_STAMPS builds), else null
 };
@@ -87,6 +88,7 @@ struct DevCtr {
   float last_losses[4];
   double loss_sum[4];
   AdamCoef coef;   // written by a spare forward block for the step in flight
+  int64_t coef_step;  // 1-based Adam step `coef` belongs to (= ctr[0] + 1 of that forward)
 };
 
 // One work-group of k_update: everything it needs, flattened (no second,

@@ -169,15 +169,18 @@ __device__ __forceinline__ void mlp_slab(const FwdNet &N, const TrainerDesc &D, 
   const int nk1 = N.k1pad / P::KM;
   const int nt3 = N.out_pad / 16;  // 1 or 2
   uint4 w1[K::NK1][TPW], w2[K::NKC][TPW], w3[K::NK3][2];
-  load_w<P, K::NK1, TPW>(w1, reinterpret_cast<const T *>(N.w1c), nk1, 0, nk1, wave * TPW, lane);
-  load_w<P, K::NKC, TPW>(w2, reinterpret_cast<const T *>(N.w2c), K::NK2, 0, K::NKC, wave * TPW, lane);
+  const T *W1 = reinterpret_cast<const T *>(N.w1c);
+  const T *W2 = reinterpret_cast<const T *>(N.w2c);
+  const T *W3 = reinterpret_cast<const T *>(N.w3c);
+  load_w<P, K::NK1, TPW>(w1, W1, nk1, 0, nk1, wave * TPW, lane);
+  load_w<P, K::NKC, TPW>(w2, W2, K::NK2, 0, K::NKC, wave * TPW, lane);
 #pragma unroll
   for (int i = 0; i < K::NK3; ++i) {
     const int ks = wave + 4 * i;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
       if (ks < K::NK2 && jt < nt3)
-        w3[i][jt] = ldg16(reinterpret_cast<const T *>(N.w3c) + frag_off<P>(jt, ks, K::NK2, lane));
+        w3[i][jt] = ldg16(W3 + frag_off<P>(jt, ks, K::NK2, lane));
   }
   float bias1[TPW], bias2[TPW];
 #pragma unroll
@@ -228,8 +231,7 @@ __device__ __forceinline__ void mlp_slab(const FwdNet &N, const TrainerDesc &D, 
     mma_w<P, K::NKC, TPW>(h1, HP, 0, K::NKC, w2, acc, lane);
 #pragma unroll 1
     for (int ch = 1; ch < K::NCH; ++ch) {
-      load_w<P, K::NKC, TPW>(w2, reinterpret_cast<const T *>(N.w2c), K::NK2, ch * K::NKC, K::NKC,
-                             wave * TPW, lane);
+      load_w<P, K::NKC, TPW>(w2, W2, K::NK2, ch * K::NKC, K::NKC, wave * TPW, lane);
       mma_w<P, K::NKC, TPW>(h1, HP, ch * K::NKC * P::KM, K::NKC, w2, acc, lane);
     }
 #pragma unroll
@@ -315,8 +317,12 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   const TrainerDesc &D = *Dp;
   if (fnet >= N_FWD) {
     // spare XCD slot: one thread prepares this step's Adam coefficients for k_update
-    if (slab == 0 && threadIdx.x == 0)
+    if (slab == 0 && threadIdx.x == 0) {
       write_adam_coef(D, *Ap, Cp->ctr[0] + 1, const_cast<AdamCoef *>(&Cp->coef));
+      const_cast<DevCtr *>(Cp)->coef_step = Cp->ctr[0] + 1;
+    }
+    if (slab == 0 && !D.deterministic && (int)threadIdx.x < D.A)
+      stg(D.ls_snap + threadIdx.x, ldg(D.params + D.off_log_std + threadIdx.x));
     return;
   }
   const DevArgs A = *Ap;
@@ -397,12 +403,68 @@ __global__ __launch_bounds__(256) void k_infer(const TrainerDesc *__restrict__ D
   mlp_slab<BF16, H>(N, D, nullptr, 0, 0, smem, out, out_stride, row0, n, [] {}, fill);
 }
 
+// ------------------------------------------------------------------------
+// d(loss)/d(out) of output j of batch row b for network `net`, plus the logged
+// loss term and (Gaussian actor) the d(loss)/d(std) term  (ref:581-637).
+// Shared by k_backward and by the update tiles that rebuild dZ2 / dZ3 on the fly:
+// identical instruction sequence, identical bits.
+// ------------------------------------------------------------------------
+template <bool BF16>
+__device__ __forceinline__ void loss_terms(const TrainerDesc &D, int net, int b, int j, float fB,
+                                           float &dz3, float &lterm, float &gstd) {
+  using P = Prec<BF16>;
+  const float *o = D.outs + (size_t)b * D.OUTW;
+  const float qt1 = ldg(o + OUT_QT1), qt2 = ldg(o + OUT_QT2), vv = ldg(o + OUT_V);
+  gstd = 0.f;
+  if (net == NET_A) {
+    const float mean = ldg(o + OUT_MEAN + j);
+    const float act = ldg(D.actf + (size_t)b * D.A + j);
+    float ls = D.deterministic ? 0.f : ldg(D.ls_snap + j);
+    const float adv = P::round(fminf(qt1, qt2) - vv);                          // ref:583-587
+    const float eadv = fminf(P::round(expf(P::round(D.beta * adv))), 100.f);   // ref:622
+    const float gbc = eadv / fB;
+    float gm, bc;
+    if (!D.deterministic) {
+      ls = fminf(fmaxf(ls, -20.f), 2.f);
+      const float sd = expf(ls), var = sd * sd, z = act - mean;
+      // -log_prob (torch.distributions.Normal.log_prob)
+      bc = (z * z) / (2.f * var) + logf(sd) + 0.9189385332046727f;
+      gm = P::round(-gbc * (z / var));
+      gstd = gbc * (-(z * z) / (var * sd) + 1.f / sd);
+    } else {
+      const float z = mean - act;  // ref:629
+      bc = z * z;
+      gm = P::round(gbc * 2.f * z);
+    }
+    lterm = eadv * bc;
+    dz3 = P::round(gm * (1.f - mean * mean));  // tanh backward
+  } else if (net == NET_V) {
+    const float adv = P::round(fminf(qt1, qt2) - vv);
+    const float w = fabsf(D.iql_tau - (adv < 0.f ? 1.f : 0.f));  // ref:404-405
+    lterm = w * P::round(adv * adv);
+    float g;
+    if constexpr (BF16)
+      g = rbf(rbf(w / fB) * (2.f * adv));
+    else
+      g = (w / fB) * (2.f * adv);
+    dz3 = -g;  // adv = target_q - v
+  } else {
+    const float nv = ldg(o + OUT_NV);
+    const float qv = ldg(o + (net == NET_Q1 ? OUT_Q1 : OUT_Q2));
+    const float rew = ldg(D.rd + (size_t)b * 2), done = ldg(D.rd + (size_t)b * 2 + 1);
+    const float target = rew + (1.f - done) * D.discount * nv;  // ref:604
+    const float diff = qv - target;
+    lterm = diff * diff;
+    dz3 = P::round(diff / fB);  // 0.5 * 2 (q - t) / B
+  }
+}
+
 // ========================================================================
 // k_backward
 // ========================================================================
 template <bool BF16, int H>
-__global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict__ Dp,
-                                                  const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp) {
+__device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp, DevCtr *__restrict__ Cp,
+                                              const int blk, char *smem) {
   using K = KCfg<BF16, H>;
   using P = Prec<BF16>;
   using T = typename P::T;
@@ -412,8 +474,8 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
   // the cheap loss / dZ2 phase, work-group 0 stores it.
   constexpr int SPLIT = K::TPW >= 2 ? 2 : 1;
   constexpr int TPH = K::TPW / SPLIT;  // n-tiles per wave in the dZ1 GEMM
-  const int xcd = blockIdx.x & 7, net = xcd >> 1;
-  const int rest = blockIdx.x >> 3;
+  const int xcd = blk & 7, net = xcd >> 1;
+  const int rest = blk >> 3;
   // SPLIT == 2: XCD 2n runs half 0 of every slab of net n, XCD 2n+1 half 1, so each L2
   // fetches only the half of W2^T its work-groups stream
   const int half = SPLIT == 2 ? (xcd & 1) : 0;
@@ -429,19 +491,20 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
   const int B = D.B, BP = D.BP, nkb = D.BP / P::KM;
   const float fB = (float)B;
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   T *dz2s = reinterpret_cast<T *>(smem);                       // [16][HP]
   float *dz3 = reinterpret_cast<float *>(dz2s + SLAB * HP);    // [16][32] d(loss)/d(out)
   float *lterm = dz3 + SLAB * 32;                              // [16][32] loss terms
   float *gstd = lterm + SLAB * 32;                             // [16][32] d(loss)/d(std) terms
   float *rowsum = gstd + SLAB * 32;                            // [16]
 
-  if (blockIdx.x == 0 && tid == 0) Cp->ctr[1] = Cp->ctr[0] + 1;
+  if (blk == 0 && tid == 0) Cp->ctr[1] = Cp->ctr[0] + 1;
   STAMP(1, 0);
 
   // ---- request everything that does not depend on the loss ----
   uint4 w2t[K::NKC][TPH];
-  load_w<P, K::NKC, TPH>(w2t, reinterpret_cast<const T *>(N.w2ct), K::NK2, 0, K::NKC, tile0, lane);
+  const T *W2T = reinterpret_cast<const T *>(N.w2ct);
+  const T *W3c = reinterpret_cast<const T *>(N.wc[2]);
+  load_w<P, K::NKC, TPH>(w2t, W2T, K::NK2, 0, K::NKC, tile0, lane);
   float h1v[TPH][4];
 #pragma unroll
   for (int jj = 0; jj < TPH; ++jj)
@@ -458,7 +521,7 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
 #pragma unroll
     for (int j = 0; j < 32; ++j)
       w3v[j] = j < N.out_dim
-                   ? P::to_f32(ldg(reinterpret_cast<const T *>(N.wc[2]) + fidx<P>(j, c2, K::NK2)))
+                   ? P::to_f32(ldg(W3c + fidx<P>(j, c2, K::NK2)))
                    : 0.f;
   }
 
@@ -466,56 +529,11 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
   STAMP(1, 1);
   for (int e = tid; e < SLAB * 32; e += 256) dz3[e] = 0.f, lterm[e] = 0.f, gstd[e] = 0.f;
   __syncthreads();
-  if (net == NET_A) {
-    for (int e = tid; e < SLAB * D.A; e += 256) {
-      const int rr = e / D.A, j = e - rr * D.A;
-      const int b = slab * SLAB + rr;
-      const float *o = D.outs + (size_t)b * D.OUTW;
-      const float qt1 = ldg(o + OUT_QT1), qt2 = ldg(o + OUT_QT2), vv = ldg(o + OUT_V);
-      const float mean = ldg(o + OUT_MEAN + j);
-      const float act = ldg(D.actf + (size_t)b * D.A + j);
-      float ls = D.deterministic ? 0.f : ldg(D.params + D.off_log_std + j);
-      const float adv = P::round(fminf(qt1, qt2) - vv);                       // ref:583-587
-      const float eadv = fminf(P::round(expf(P::round(D.beta * adv))), 100.f);  // ref:622
-      const float gbc = eadv / fB;
-      float gm, bc;
-      if (!D.deterministic) {
-        ls = fminf(fmaxf(ls, -20.f), 2.f);
-        const float sd = expf(ls), var = sd * sd, z = act - mean;
-        // -log_prob (torch.distributions.Normal.log_prob)
-        bc = (z * z) / (2.f * var) + logf(sd) + 0.9189385332046727f;
-        gm = P::round(-gbc * (z / var));
-        gstd[rr * 32 + j] = gbc * (-(z * z) / (var * sd) + 1.f / sd);
-      } else {
-        const float z = mean - act;  // ref:629
-        bc = z * z;
-        gm = P::round(gbc * 2.f * z);
-      }
-      lterm[rr * 32 + j] = eadv * bc;
-      dz3[rr * 32 + j] = P::round(gm * (1.f - mean * mean));  // tanh backward
-    }
-  } else if (tid < SLAB) {
-    const int b = slab * SLAB + tid;
-    const float *o = D.outs + (size_t)b * D.OUTW;
-    const float qt1 = ldg(o + OUT_QT1), qt2 = ldg(o + OUT_QT2), vv = ldg(o + OUT_V), nv = ldg(o + OUT_NV);
-    const float qv = ldg(o + (net == NET_Q1 ? OUT_Q1 : OUT_Q2));
-    const float rew = ldg(D.rd + (size_t)b * 2), done = ldg(D.rd + (size_t)b * 2 + 1);
-    if (net == NET_V) {
-      const float adv = P::round(fminf(qt1, qt2) - vv);
-      const float w = fabsf(D.iql_tau - (adv < 0.f ? 1.f : 0.f));  // ref:404-405
-      lterm[tid * 32] = w * P::round(adv * adv);
-      float g;
-      if constexpr (BF16)
-        g = rbf(rbf(w / fB) * (2.f * adv));
-      else
-        g = (w / fB) * (2.f * adv);
-      dz3[tid * 32] = -g;  // adv = target_q - v
-    } else {
-      const float target = rew + (1.f - done) * D.discount * nv;  // ref:604
-      const float diff = qv - target;
-      lterm[tid * 32] = diff * diff;
-      dz3[tid * 32] = P::round(diff / fB);  // 0.5 * 2 (q - t) / B
-    }
+  for (int e = tid; e < SLAB * N.out_dim; e += 256) {
+    const int rr = e / N.out_dim, j = e - rr * N.out_dim;
+    float d3, lt, gs;
+    loss_terms<BF16>(D, net, slab * SLAB + rr, j, fB, d3, lt, gs);
+    dz3[rr * 32 + j] = d3, lterm[rr * 32 + j] = lt, gstd[rr * 32 + j] = gs;
   }
   __syncthreads();
   STAMP(1, 2);
@@ -584,8 +602,7 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
     mma_w<P, K::NKC, TPH>(dz2s, HP, 0, K::NKC, w2t, acc, lane);
 #pragma unroll 1
     for (int ch = 1; ch < K::NCH; ++ch) {
-      load_w<P, K::NKC, TPH>(w2t, reinterpret_cast<const T *>(N.w2ct), K::NK2, ch * K::NKC, K::NKC,
-                             tile0, lane);
+      load_w<P, K::NKC, TPH>(w2t, W2T, K::NK2, ch * K::NKC, K::NKC, tile0, lane);
       mma_w<P, K::NKC, TPH>(dz2s, HP, ch * K::NKC * P::KM, K::NKC, w2t, acc, lane);
     }
 #pragma unroll
@@ -670,9 +687,10 @@ constexpr int URPP = 256 / UTPR; // rows per pass
 constexpr int UNP = UTO / URPP;  // passes
 
 template <bool BF16>
-__global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ Dp,
-                                                const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
-                                                const UpdItem *__restrict__ items, int n_items) {
+__device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
+                                            const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
+                                            const UpdItem *__restrict__ items, int n_items,
+                                            const int blk) {
   using P = Prec<BF16>;
   using T = typename P::T;
   const TrainerDesc &D = *Dp;
@@ -681,7 +699,7 @@ __global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ 
   const int r = lane & 15, q = lane >> 4;
   const int H = D.H, B = D.B, BP = D.BP;
   const int nslab = B / SLAB;
-  const int64_t t1 = Cp->ctr[1];  // 1-based Adam step of this update
+  const int64_t t1 = Cp->coef_step;  // 1-based Adam step of this update (set by k_forward)
   const AdamCoef coef = Cp->coef;
 
   __shared__ __attribute__((aligned(16))) float tile[UTO * ULD];  // [o][i] gradient, then new weights
@@ -689,7 +707,7 @@ __global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ 
   static_assert(UTO * ULD >= 1024, "the misc block reuses the tile as its reduction buffer");
   STAMP(2, 0);
 
-  if ((int)blockIdx.x >= n_items) {
+  if (blk >= n_items) {
     // ---------------- misc block: log_std, logged losses, step counter ------------
     // all partials are fetched in parallel, then summed in a fixed order from LDS
     float *sred = tile;
@@ -735,7 +753,7 @@ __global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ 
     return;
   }
 
-  const UpdItem it = items[blockIdx.x];
+  const UpdItem it = items[blk];
   if (it.net < 0) return;  // padding slot of the XCD-major item table
   const int L = it.layer;
   const int Odim = it.Odim, Idim = it.Idim, Kw = it.Kw, Opad = it.Opad;
@@ -925,6 +943,23 @@ __global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ 
     }
   }
   STAMP(2, 4);
+}
+
+// ------------------------------------------------------------------------
+// __global__ wrappers
+// ------------------------------------------------------------------------
+template <bool BF16, int H>
+__global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict__ Dp,
+                                                  const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  backward_body<BF16, H>(Dp, Cp, (int)blockIdx.x, smem);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ Dp,
+                                                const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
+                                                const UpdItem *__restrict__ items, int n_items) {
+  update_body<BF16>(Dp, Ap, Cp, items, n_items, (int)blockIdx.x);
 }
 
 // ========================================================================

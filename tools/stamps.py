@@ -85,3 +85,22 @@ if "--hist" in sys.argv:
     for b in used[order][-24:]:
         s = [(w[b, k] - t0) * 10 if w[b, k] > 0 else -1 for k in range(5)]
         print(f"  {b:3d} x{b%8} start {s[0]:6.0f}  {s[1]-s[0]:6.0f} {s[3]-s[1]:6.0f} {s[4]-s[3]:6.0f}  end {s[4]:6.0f}")
+
+if "--upda" in sys.argv:
+    w = d[2, :, :, 0]
+    t0 = d[0, :, 0, 0][d[0, :, 0, 0] > 0].min()
+    print("update-stamp slots >= 128 (merged launch tiles): blk start s0->1 s1->3 s3->4 end (ns from forward start)")
+    for b in range(128, 512):
+        if w[b, 0] > 0 and w[b, 4] > 0:
+            s_ = [(w[b, k] - t0) * 10 if w[b, k] > 0 else -1 for k in range(5)]
+            if b % 6 == 0:
+                print(f"  {b:3d} x{b%8} start {s_[0]:6.0f}  {s_[1]-s_[0]:6.0f} {s_[3]-s_[1]:6.0f} {s_[4]-s_[3]:6.0f}  end {s_[4]:6.0f}")
+
+if "--upda2" in sys.argv:
+    w = d[2, :, :, 0]
+    t0 = d[0, :, 0, 0][d[0, :, 0, 0] > 0].min()
+    print("merged-launch tiles: blk start | 0->1 state issue | 1->2 dz3 | 2->5 frag issue | 5->6 gen | 6->3 mma+tile | 3->4 adam")
+    for b in range(128, 512, 7):
+        if w[b, 0] > 0 and w[b, 4] > 0:
+            g = lambda k: (w[b, k] - t0) * 10
+            print(f"  {b:3d} x{b%8} start {g(0):6.0f} | {g(1)-g(0):6.0f} {g(2)-g(1):6.0f} {g(5)-g(2):6.0f} {g(6)-g(5):6.0f} {g(3)-g(6):6.0f} {g(4)-g(3):6.0f}")
