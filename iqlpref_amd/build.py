@@ -18,17 +18,21 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
+def build(force=False, verbose=True, stamps=False):
+    """stamps=True builds the diagnostic libiqlhip_stamps.so (tools/stamps.py), never the product."""
+    if not stamps and not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = LIB.replace(".so", "_stamps.so") if stamps else LIB
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wno-unused-value", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    if stamps:
+        cmd.insert(1, "-DIQL_STAMPS")
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, stamps="--stamps" in sys.argv)
