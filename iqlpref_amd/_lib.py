@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libiqlhip.so")
+# IQLHIP_LIB: load another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("IQLHIP_LIB") or os.path.join(HERE, "libiqlhip.so")
 
 PREC_FP32 = 0
 PREC_BF16 = 1

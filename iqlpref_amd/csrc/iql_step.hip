@@ -685,6 +685,9 @@ constexpr int ULD = UTI + 4;     // LDS row stride (floats)
 constexpr int UTPR = UTI / 4;    // threads per tile row (float4 each)
 constexpr int URPP = 256 / UTPR; // rows per pass
 constexpr int UNP = UTO / URPP;  // passes
+constexpr int UMAXI = 128;       // S + A <= 128 (host check)
+constexpr int UNIT = UMAXI / 16; // in-feature tiles of a layer-1 strip, at most
+constexpr int UNFL = 12;         // flat-range elements per thread held in registers (S + A <= 48)
 
 template <bool BF16>
 __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
@@ -702,7 +705,8 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   const int64_t t1 = Cp->coef_step;  // 1-based Adam step of this update (set by k_forward)
   const AdamCoef coef = Cp->coef;
 
-  __shared__ __attribute__((aligned(16))) float tile[UTO * ULD];  // [o][i] gradient, then new weights
+  // [o][i] gradient, then new weights; sized for a layer-1 strip (64 x all in-features)
+  __shared__ __attribute__((aligned(16))) float tile[UTO * (UMAXI + 4)];
   __shared__ float bgrad[UTO];
   static_assert(UTO * ULD >= 1024, "the misc block reuses the tile as its reduction buffer");
   STAMP(2, 0);
@@ -759,10 +763,128 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   const int Odim = it.Odim, Idim = it.Idim, Kw = it.Kw, Opad = it.Opad;
   const int Ipad = round_up(Idim, 16);
   const int o0 = it.o0, i0 = it.i0;
-  const bool vec = (Idim & 3) == 0;  // rows of the fp32 masters are 16-byte aligned
   const float neg_step =
       it.group == 0 ? coef.neg_step[0] : (it.group == 1 ? coef.neg_step[1] : coef.neg_step[2]);
   const bool has_target = it.has_target != 0;
+  const int nk = BP / P::KM;
+
+  if (L == 0) {
+    // =========== layer 1: a strip of 64 out-features x ALL in-features ===========
+    // Rows of W1 (S + A floats) are not 16-byte aligned, so the strip's optimiser state is
+    // streamed as ONE flat range o0*Idim .. (o0+64)*Idim: consecutive lanes, consecutive
+    // addresses, every line fully used.
+    const int TLD = Ipad + 4;
+    const int nflat = (Odim - o0 < UTO ? Odim - o0 : UTO) * Idim;
+    const int64_t fbase = it.off_w + (int64_t)o0 * Idim, tbase = it.toff_w + (int64_t)o0 * Idim;
+    float pf[UNFL], mf[UNFL], vf[UNFL], tf[UNFL];
+#pragma unroll
+    for (int k = 0; k < UNFL; ++k) {
+      const int e = tid + 256 * k;
+      pf[k] = mf[k] = vf[k] = tf[k] = 0.f;
+      if (e < nflat) {
+        pf[k] = ldg(D.params + fbase + e), mf[k] = ldg(D.exp_avg + fbase + e);
+        vf[k] = ldg(D.exp_avg_sq + fbase + e);
+        if (has_target) tf[k] = ldg(D.target + tbase + e);
+      }
+    }
+    float pb = 0.f, mb = 0.f, vb = 0.f, tb = 0.f;
+    if (tid < UTO && o0 + tid < Odim) {
+      const int64_t eb = it.off_b + o0 + tid;
+      pb = ldg(D.params + eb), mb = ldg(D.exp_avg + eb), vb = ldg(D.exp_avg_sq + eb);
+      if (has_target) tb = ldg(D.target + it.toff_b + o0 + tid);
+    }
+    STAMP(2, 1);
+    // dW1^T strip: wave w = out-feature tile w against every in-feature tile (dZ1^T fragments
+    // stay in registers across the in-feature tiles)
+    const T *Xsrc = reinterpret_cast<const T *>(it.Xsrc);
+    const T *Zsrc = reinterpret_cast<const T *>(it.Zsrc);
+    const int nit = Ipad >> 4;
+    const bool zon = o0 + 16 * wave < Opad;
+    f32x4 acc[UNIT];
+#pragma unroll
+    for (int t = 0; t < UNIT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+#pragma unroll 1
+    for (int k0 = 0; k0 < nk; k0 += UKC) {
+      uint4 zf[UKC], xf[2][UKC];
+#pragma unroll
+      for (int ks = 0; ks < UKC; ++ks)
+        if (k0 + ks < nk && zon) {
+          zf[ks] = ldg16(Zsrc + frag_off<P>((o0 >> 4) + wave, k0 + ks, nk, lane));
+          xf[0][ks] = ldg16(Xsrc + frag_off<P>(0, k0 + ks, nk, lane));
+        }
+#pragma unroll
+      for (int t = 0; t < UNIT; ++t) {
+        if (t < nit && zon) {
+          if (t + 1 < UNIT && t + 1 < nit) {
+#pragma unroll
+            for (int ks = 0; ks < UKC; ++ks)
+              if (k0 + ks < nk) xf[(t + 1) & 1][ks] = ldg16(Xsrc + frag_off<P>(t + 1, k0 + ks, nk, lane));
+          }
+#pragma unroll
+          for (int ks = 0; ks < UKC; ++ks) {
+            if (k0 + ks < nk) {
+              if (t == 0) {  // bias gradient = row sums of dZ^T
+                if constexpr (BF16) {
+                  const uint32_t w[4] = {zf[ks].x, zf[ks].y, zf[ks].z, zf[ks].w};
+#pragma unroll
+                  for (int i = 0; i < 4; ++i)
+                    bsum += bf2f((uint16_t)(w[i] & 0xffff)) + bf2f((uint16_t)(w[i] >> 16));
+                } else {
+                  const float4 f = __builtin_bit_cast(float4, zf[ks]);
+                  bsum += (f.x + f.y) + (f.z + f.w);
+                }
+              }
+              P::mma(xf[t & 1][ks], zf[ks], acc[t]);
+            }
+          }
+        }
+      }
+    }
+    // C/D layout: lane (r, q) of acc[t] holds dW[o0 + 16 wave + r][16 t + 4 q + k]
+#pragma unroll
+    for (int t = 0; t < UNIT; ++t)
+      if (t < nit) *reinterpret_cast<f32x4 *>(&tile[(16 * wave + r) * TLD + 16 * t + 4 * q]) = acc[t];
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (q == 0) bgrad[16 * wave + r] = bsum;
+    __syncthreads();
+    STAMP(2, 3);
+    T *wc = reinterpret_cast<T *>(it.wc);
+    T *tc = reinterpret_cast<T *>(it.tc);
+    const int nkw = Kw / P::KM;
+    auto flat_update = [&](int e, float p, float m, float v, float tv0) {
+      const int ol = e / Idim, i = e - ol * Idim;
+      const float g = P::round(tile[ol * TLD + i]);
+      adam_apply(p, m, v, g, coef, neg_step);
+      stg(D.params + fbase + e, p), stg(D.exp_avg + fbase + e, m), stg(D.exp_avg_sq + fbase + e, v);
+      if (D.grads) stg(D.grads + fbase + e, g);
+      stg(wc + fidx<P>(o0 + ol, i, nkw), P::from_f32(p));
+      if (has_target) {
+        const float tv = tv0 + D.tau * (p - tv0);  // lerp_ (ref:127-129)
+        stg(D.target + tbase + e, tv);
+        stg(tc + fidx<P>(o0 + ol, i, nkw), P::from_f32(tv));
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < UNFL; ++k) {
+      const int e = tid + 256 * k;
+      if (e < nflat) flat_update(e, pf[k], mf[k], vf[k], tf[k]);
+    }
+    for (int e = tid + 256 * UNFL; e < nflat; e += 256)  // wide inputs (S + A > 48): from memory
+      flat_update(e, ldg(D.params + fbase + e), ldg(D.exp_avg + fbase + e), ldg(D.exp_avg_sq + fbase + e),
+                  has_target ? ldg(D.target + tbase + e) : 0.f);
+    if (tid < UTO && o0 + tid < Odim) {
+      const int64_t e = it.off_b + o0 + tid;
+      const float g = P::round(bgrad[tid]);
+      adam_apply(pb, mb, vb, g, coef, neg_step);
+      stg(D.params + e, pb), stg(D.exp_avg + e, mb), stg(D.exp_avg_sq + e, vb);
+      if (D.grads) stg(D.grads + e, g);
+      if (has_target) stg(D.target + it.toff_b + o0 + tid, tb + D.tau * (pb - tb));
+    }
+    STAMP(2, 4);
+    return;
+  }
 
   // ---- 1. optimiser state, row order: thread -> (row tr + 16 pass, columns 4 tc .. +3) ----
   const int tr = tid / UTPR, tc4 = (tid % UTPR) * 4;
@@ -775,26 +897,16 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     if (o < Odim && i < Idim) {
       const int64_t e = it.off_w + (int64_t)o * Idim + i;
       const int64_t te = it.toff_w + (int64_t)o * Idim + i;
-      if (vec) {
-        const float4 a4 = __builtin_bit_cast(float4, ldg16(D.params + e));
-        const float4 b4 = __builtin_bit_cast(float4, ldg16(D.exp_avg + e));
-        const float4 c4 = __builtin_bit_cast(float4, ldg16(D.exp_avg_sq + e));
-        pw[ps][0] = a4.x, pw[ps][1] = a4.y, pw[ps][2] = a4.z, pw[ps][3] = a4.w;
-        mw[ps][0] = b4.x, mw[ps][1] = b4.y, mw[ps][2] = b4.z, mw[ps][3] = b4.w;
-        vw[ps][0] = c4.x, vw[ps][1] = c4.y, vw[ps][2] = c4.z, vw[ps][3] = c4.w;
-        if (has_target) {
-          const float4 d4 = __builtin_bit_cast(float4, ldg16(D.target + te));
-          tw[ps][0] = d4.x, tw[ps][1] = d4.y, tw[ps][2] = d4.z, tw[ps][3] = d4.w;
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (i + k < Idim) {
-            pw[ps][k] = ldg(D.params + e + k), mw[ps][k] = ldg(D.exp_avg + e + k);
-            vw[ps][k] = ldg(D.exp_avg_sq + e + k);
-            if (has_target) tw[ps][k] = ldg(D.target + te + k);
-          }
-        }
+      // Idim = H here: rows of the fp32 masters are 16-byte aligned
+      const float4 a4 = __builtin_bit_cast(float4, ldg16(D.params + e));
+      const float4 b4 = __builtin_bit_cast(float4, ldg16(D.exp_avg + e));
+      const float4 c4 = __builtin_bit_cast(float4, ldg16(D.exp_avg_sq + e));
+      pw[ps][0] = a4.x, pw[ps][1] = a4.y, pw[ps][2] = a4.z, pw[ps][3] = a4.w;
+      mw[ps][0] = b4.x, mw[ps][1] = b4.y, mw[ps][2] = b4.z, mw[ps][3] = b4.w;
+      vw[ps][0] = c4.x, vw[ps][1] = c4.y, vw[ps][2] = c4.z, vw[ps][3] = c4.w;
+      if (has_target) {
+        const float4 d4 = __builtin_bit_cast(float4, ldg16(D.target + te));
+        tw[ps][0] = d4.x, tw[ps][1] = d4.y, tw[ps][2] = d4.z, tw[ps][3] = d4.w;
       }
     }
   }
@@ -815,7 +927,6 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   const int ib = i0 + 16 * wi, ob = o0 + 32 * wo;
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   float bsum[2] = {0.f, 0.f};
-  const int nk = BP / P::KM;
   const bool wave_bias = do_bias && wi == 0;
   const bool xon = ib < Ipad;
   const bool zon[2] = {ob < Opad, ob + 16 < Opad};
@@ -895,29 +1006,14 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     if (o < Odim && i < Idim) {
       const int64_t e = it.off_w + (int64_t)o * Idim + i;
       const int64_t te = it.toff_w + (int64_t)o * Idim + i;
-      if (vec) {
-        stg16(D.params + e, make_float4(p[0], p[1], p[2], p[3]));
-        stg16(D.exp_avg + e, make_float4(m[0], m[1], m[2], m[3]));
-        stg16(D.exp_avg_sq + e, make_float4(v[0], v[1], v[2], v[3]));
-        if (D.grads) stg16(D.grads + e, make_float4(g[0], g[1], g[2], g[3]));
-        if (has_target) stg16(D.target + te, make_float4(tv[0], tv[1], tv[2], tv[3]));
-        // 4 consecutive k of one row are contiguous in the fragment-major copies
-        store4T<BF16>(wc + fidx<P>(o, i, nkw), p);
-        if (has_target) store4T<BF16>(tc + fidx<P>(o, i, nkw), tv);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (i + k < Idim) {
-            stg(D.params + e + k, p[k]), stg(D.exp_avg + e + k, m[k]), stg(D.exp_avg_sq + e + k, v[k]);
-            if (D.grads) stg(D.grads + e + k, g[k]);
-            stg(wc + fidx<P>(o, i + k, nkw), P::from_f32(p[k]));
-            if (has_target) {
-              stg(D.target + te + k, tv[k]);
-              stg(tc + fidx<P>(o, i + k, nkw), P::from_f32(tv[k]));
-            }
-          }
-        }
-      }
+      stg16(D.params + e, make_float4(p[0], p[1], p[2], p[3]));
+      stg16(D.exp_avg + e, make_float4(m[0], m[1], m[2], m[3]));
+      stg16(D.exp_avg_sq + e, make_float4(v[0], v[1], v[2], v[3]));
+      if (D.grads) stg16(D.grads + e, make_float4(g[0], g[1], g[2], g[3]));
+      if (has_target) stg16(D.target + te, make_float4(tv[0], tv[1], tv[2], tv[3]));
+      // 4 consecutive k of one row are contiguous in the fragment-major copies
+      store4T<BF16>(wc + fidx<P>(o, i, nkw), p);
+      if (has_target) store4T<BF16>(tc + fidx<P>(o, i, nkw), tv);
     }
   }
   // ---- bias: thread t < 64 owns out-feature o0 + t ----
