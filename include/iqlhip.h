@@ -95,7 +95,9 @@ typedef struct {
   uint64_t seed;         /* Philox key for on-device indices and dropout          */
 } iqlhip_trainer_config;
 
-/* Number of fp32 elements and the element offset of every tensor in the
+/* Number of fp32 elements of the arenas (n_params, n_target: they include the
+ * alignment padding, every tensor starts on a 128-byte line; padding elements
+ * are never read or written) and the element offset of every tensor in the
  * parameter arena.  Order of the 25 offsets: for net in (q1, q2, v, actor):
  * W1[H][in] b1[H] W2[H][H] b2[H] W3[out][H] b3[out]; then actor log_std[A]
  * (offset -1 when deterministic).  Torch [out][in] row-major layouts.

@@ -140,33 +140,42 @@ static int check_cfg(const iqlhip_trainer_config *c) {
 
 struct Layout {
   int64_t off[IQLHIP_N_TENSORS];
-  int64_t n_params, n_target;
+  int64_t n_params, n_target;      // arena elements (with alignment padding)
+  int64_t true_params, true_target;  // trained scalars (SURVEY 8d byte model)
 };
 static void net_dims(const iqlhip_trainer_config &c, int net, int *in, int *out) {
   *in = (net == NET_Q1 || net == NET_Q2) ? c.state_dim + c.action_dim : c.state_dim;
   *out = (net == NET_A) ? c.action_dim : 1;
 }
 static Layout make_layout(const iqlhip_trainer_config &c) {
+  // every tensor starts on a 128-byte line: rows of the H-wide matrices and the flat layer-1
+  // strips are then streamed in whole, aligned lines
+  constexpr int64_t ALIGN = 32;
   Layout L;
-  int64_t o = 0;
+  int64_t o = 0, cnt = 0;
   const int H = c.hidden_dim;
   for (int n = 0; n < N_TRAIN; ++n) {
     int in, out;
     net_dims(c, n, &in, &out);
     const int64_t sz[6] = {(int64_t)H * in, H, (int64_t)H * H, H, (int64_t)out * H, out};
     for (int k = 0; k < 6; ++k) {
+      o = (o + ALIGN - 1) / ALIGN * ALIGN;
       L.off[n * 6 + k] = o;
       o += sz[k];
+      cnt += sz[k];
     }
-    if (n == NET_Q2) L.n_target = o;
+    if (n == NET_Q2) L.n_target = o, L.true_target = cnt;
   }
   if (c.deterministic) {
     L.off[24] = -1;
   } else {
+    o = (o + ALIGN - 1) / ALIGN * ALIGN;
     L.off[24] = o;
     o += c.action_dim;
+    cnt += c.action_dim;
   }
   L.n_params = o;
+  L.true_params = cnt;
   return L;
 }
 
@@ -185,7 +194,7 @@ extern "C" int iqlhip_step_cost(const iqlhip_trainer_config *cfg, double *bytes,
   const Layout L = make_layout(*cfg);
   const double B = cfg->batch_size, S = cfg->state_dim, A = cfg->action_dim, H = cfg->hidden_dim;
   // gather + (read p,g,m,v; write g,p,m,v) per trained parameter + target r/w
-  if (bytes) *bytes = 4.0 * B * (2 * S + A + 2) + 32.0 * (double)L.n_params + 8.0 * (double)L.n_target;
+  if (bytes) *bytes = 4.0 * B * (2 * S + A + 2) + 32.0 * (double)L.true_params + 8.0 * (double)L.true_target;
   if (flops) {
     const double wv = S * H + H * H + H, wq = (S + A) * H + H * H + H, wa = S * H + H * H + H * A;
     const double fwd = 2 * wv + 4 * wq + wa;                     // V twice, target+online twin Q, actor

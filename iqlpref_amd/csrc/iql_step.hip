@@ -687,7 +687,7 @@ constexpr int URPP = 256 / UTPR; // rows per pass
 constexpr int UNP = UTO / URPP;  // passes
 constexpr int UMAXI = 128;       // S + A <= 128 (host check)
 constexpr int UNIT = UMAXI / 16; // in-feature tiles of a layer-1 strip, at most
-constexpr int UNFL = 12;         // flat-range elements per thread held in registers (S + A <= 48)
+constexpr int UNF4 = 3;          // float4 of the flat range per thread held in registers (S + A <= 48)
 
 template <bool BF16>
 __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
@@ -707,6 +707,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 
   // [o][i] gradient, then new weights; sized for a layer-1 strip (64 x all in-features)
   __shared__ __attribute__((aligned(16))) float tile[UTO * (UMAXI + 4)];
+  __shared__ __attribute__((aligned(16))) float tile2[UTO * (UMAXI + 4)];  // layer-1 strip: new targets
   __shared__ float bgrad[UTO];
   static_assert(UTO * ULD >= 1024, "the misc block reuses the tile as its reduction buffer");
   STAMP(2, 0);
@@ -774,17 +775,18 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     // streamed as ONE flat range o0*Idim .. (o0+64)*Idim: consecutive lanes, consecutive
     // addresses, every line fully used.
     const int TLD = Ipad + 4;
-    const int nflat = (Odim - o0 < UTO ? Odim - o0 : UTO) * Idim;
+    const int n4 = UTO * Idim / 4;  // Odim = H is a multiple of 64: the strip is always 64 full rows
     const int64_t fbase = it.off_w + (int64_t)o0 * Idim, tbase = it.toff_w + (int64_t)o0 * Idim;
-    float pf[UNFL], mf[UNFL], vf[UNFL], tf[UNFL];
+    float4 pf[UNF4], mf[UNF4], vf[UNF4], tf[UNF4];
 #pragma unroll
-    for (int k = 0; k < UNFL; ++k) {
-      const int e = tid + 256 * k;
-      pf[k] = mf[k] = vf[k] = tf[k] = 0.f;
-      if (e < nflat) {
-        pf[k] = ldg(D.params + fbase + e), mf[k] = ldg(D.exp_avg + fbase + e);
-        vf[k] = ldg(D.exp_avg_sq + fbase + e);
-        if (has_target) tf[k] = ldg(D.target + tbase + e);
+    for (int k = 0; k < UNF4; ++k) {
+      const int e4 = tid + 256 * k;
+      pf[k] = mf[k] = vf[k] = tf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e4 < n4) {
+        pf[k] = __builtin_bit_cast(float4, ldg16(D.params + fbase + 4 * e4));
+        mf[k] = __builtin_bit_cast(float4, ldg16(D.exp_avg + fbase + 4 * e4));
+        vf[k] = __builtin_bit_cast(float4, ldg16(D.exp_avg_sq + fbase + 4 * e4));
+        if (has_target) tf[k] = __builtin_bit_cast(float4, ldg16(D.target + tbase + 4 * e4));
       }
     }
     float pb = 0.f, mb = 0.f, vb = 0.f, tb = 0.f;
@@ -853,27 +855,40 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     T *wc = reinterpret_cast<T *>(it.wc);
     T *tc = reinterpret_cast<T *>(it.tc);
     const int nkw = Kw / P::KM;
-    auto flat_update = [&](int e, float p, float m, float v, float tv0) {
-      const int ol = e / Idim, i = e - ol * Idim;
-      const float g = P::round(tile[ol * TLD + i]);
-      adam_apply(p, m, v, g, coef, neg_step);
-      stg(D.params + fbase + e, p), stg(D.exp_avg + fbase + e, m), stg(D.exp_avg_sq + fbase + e, v);
-      if (D.grads) stg(D.grads + fbase + e, g);
-      stg(wc + fidx<P>(o0 + ol, i, nkw), P::from_f32(p));
-      if (has_target) {
-        const float tv = tv0 + D.tau * (p - tv0);  // lerp_ (ref:127-129)
-        stg(D.target + tbase + e, tv);
-        stg(tc + fidx<P>(o0 + ol, i, nkw), P::from_f32(tv));
+    // Adam + Polyak on the flat range, four consecutive elements per access; the new weights
+    // (and targets) go back to LDS in [row][in-feature] order for the compute copies
+    auto flat_update = [&](int e4, float4 p4, float4 m4, float4 v4, float4 t4) {
+      float p[4] = {p4.x, p4.y, p4.z, p4.w}, m[4] = {m4.x, m4.y, m4.z, m4.w};
+      float v[4] = {v4.x, v4.y, v4.z, v4.w}, tv[4] = {t4.x, t4.y, t4.z, t4.w}, g[4];
+      int ol = (4 * e4) / Idim, i = 4 * e4 - ol * Idim;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        g[k] = P::round(tile[ol * TLD + i]);
+        adam_apply(p[k], m[k], v[k], g[k], coef, neg_step);
+        tile[ol * TLD + i] = p[k];
+        if (has_target) {
+          tv[k] = tv[k] + D.tau * (p[k] - tv[k]);  // lerp_ (ref:127-129)
+          tile2[ol * TLD + i] = tv[k];
+        }
+        if (++i == Idim) i = 0, ++ol;
       }
+      stg16(D.params + fbase + 4 * e4, make_float4(p[0], p[1], p[2], p[3]));
+      stg16(D.exp_avg + fbase + 4 * e4, make_float4(m[0], m[1], m[2], m[3]));
+      stg16(D.exp_avg_sq + fbase + 4 * e4, make_float4(v[0], v[1], v[2], v[3]));
+      if (D.grads) stg16(D.grads + fbase + 4 * e4, make_float4(g[0], g[1], g[2], g[3]));
+      if (has_target) stg16(D.target + tbase + 4 * e4, make_float4(tv[0], tv[1], tv[2], tv[3]));
     };
 #pragma unroll
-    for (int k = 0; k < UNFL; ++k) {
-      const int e = tid + 256 * k;
-      if (e < nflat) flat_update(e, pf[k], mf[k], vf[k], tf[k]);
+    for (int k = 0; k < UNF4; ++k) {
+      const int e4 = tid + 256 * k;
+      if (e4 < n4) flat_update(e4, pf[k], mf[k], vf[k], tf[k]);
     }
-    for (int e = tid + 256 * UNFL; e < nflat; e += 256)  // wide inputs (S + A > 48): from memory
-      flat_update(e, ldg(D.params + fbase + e), ldg(D.exp_avg + fbase + e), ldg(D.exp_avg_sq + fbase + e),
-                  has_target ? ldg(D.target + tbase + e) : 0.f);
+    for (int e4 = tid + 256 * UNF4; e4 < n4; e4 += 256)  // wide inputs (S + A > 48): from memory
+      flat_update(e4, __builtin_bit_cast(float4, ldg16(D.params + fbase + 4 * e4)),
+                  __builtin_bit_cast(float4, ldg16(D.exp_avg + fbase + 4 * e4)),
+                  __builtin_bit_cast(float4, ldg16(D.exp_avg_sq + fbase + 4 * e4)),
+                  has_target ? __builtin_bit_cast(float4, ldg16(D.target + tbase + 4 * e4))
+                             : make_float4(0.f, 0.f, 0.f, 0.f));
     if (tid < UTO && o0 + tid < Odim) {
       const int64_t e = it.off_b + o0 + tid;
       const float g = P::round(bgrad[tid]);
@@ -881,6 +896,22 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       stg(D.params + e, pb), stg(D.exp_avg + e, mb), stg(D.exp_avg_sq + e, vb);
       if (D.grads) stg(D.grads + e, g);
       if (has_target) stg(D.target + it.toff_b + o0 + tid, tb + D.tau * (pb - tb));
+    }
+    __syncthreads();
+    // compute copies: 4 consecutive in-features of one row are contiguous in the fragment-major
+    // image (columns Idim .. Ipad of the tile hold zero gradients = the copies' zero padding)
+    const int cpr = Ipad >> 2;
+    for (int e = tid; e < UTO * cpr; e += 256) {
+      const int ol = e / cpr, i = (e - ol * cpr) * 4;
+      const float4 p4 = *reinterpret_cast<const float4 *>(&tile[ol * TLD + i]);
+      float pv4[4] = {p4.x, p4.y, p4.z, p4.w};
+      store4T<BF16>(wc + fidx<P>(o0 + ol, i, nkw), pv4);
+      if (has_target) {
+        const float4 t4 = *reinterpret_cast<const float4 *>(&tile2[ol * TLD + i]);
+        float tv4[4] = {i < Idim ? t4.x : 0.f, i + 1 < Idim ? t4.y : 0.f, i + 2 < Idim ? t4.z : 0.f,
+                        i + 3 < Idim ? t4.w : 0.f};
+        store4T<BF16>(tc + fidx<P>(o0 + ol, i, nkw), tv4);
+      }
     }
     STAMP(2, 4);
     return;

@@ -62,9 +62,10 @@ for k in range(3):
         print(line)
 
 if "--detail" in sys.argv:
-    w = d[2, :, :, 0]
+    kd = int(os.environ.get("STAMP_KERNEL", "2"))
+    w = d[kd, :, :, 0]
     used = np.where(w[:, 0] > 0)[0]
     t0 = w[used, 0].min()
     for b in used:
         row = [(w[b, s] - t0) * 10 if w[b, s] > 0 else -1 for s in range(8)]
-        print(f"upd block {b:3d} xcd {b % 8}: " + " ".join(f"{x:7.0f}" for x in row))
+        print(f"{names[kd]} block {b:3d} xcd {b % 8}: " + " ".join(f"{x:7.0f}" for x in row))
