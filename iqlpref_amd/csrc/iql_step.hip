@@ -409,17 +409,37 @@ __global__ __launch_bounds__(256) void k_infer(const TrainerDesc *__restrict__ D
 // Shared by k_backward and by the update tiles that rebuild dZ2 / dZ3 on the fly:
 // identical instruction sequence, identical bits.
 // ------------------------------------------------------------------------
+struct LossIn {
+  float qt1, qt2, vv, mean, act, ls, nv, qv, rew, done;
+};
+
+// the loads of loss_terms, separated so that k_backward can issue them before its weight stream
+__device__ __forceinline__ LossIn loss_inputs(const TrainerDesc &D, int net, int b, int j) {
+  const float *o = D.outs + (size_t)b * D.OUTW;
+  LossIn x;
+  x.qt1 = ldg(o + OUT_QT1), x.qt2 = ldg(o + OUT_QT2), x.vv = ldg(o + OUT_V);
+  x.mean = x.act = x.ls = x.nv = x.qv = x.rew = x.done = 0.f;
+  if (net == NET_A) {
+    x.mean = ldg(o + OUT_MEAN + j);
+    x.act = ldg(D.actf + (size_t)b * D.A + j);
+    x.ls = D.deterministic ? 0.f : ldg(D.ls_snap + j);
+  } else if (net != NET_V) {
+    x.nv = ldg(o + OUT_NV);
+    x.qv = ldg(o + (net == NET_Q1 ? OUT_Q1 : OUT_Q2));
+    x.rew = ldg(D.rd + (size_t)b * 2), x.done = ldg(D.rd + (size_t)b * 2 + 1);
+  }
+  return x;
+}
+
 template <bool BF16>
-__device__ __forceinline__ void loss_terms(const TrainerDesc &D, int net, int b, int j, float fB,
+__device__ __forceinline__ void loss_terms(const TrainerDesc &D, int net, const LossIn &x, float fB,
                                            float &dz3, float &lterm, float &gstd) {
   using P = Prec<BF16>;
-  const float *o = D.outs + (size_t)b * D.OUTW;
-  const float qt1 = ldg(o + OUT_QT1), qt2 = ldg(o + OUT_QT2), vv = ldg(o + OUT_V);
+  const float qt1 = x.qt1, qt2 = x.qt2, vv = x.vv;
   gstd = 0.f;
   if (net == NET_A) {
-    const float mean = ldg(o + OUT_MEAN + j);
-    const float act = ldg(D.actf + (size_t)b * D.A + j);
-    float ls = D.deterministic ? 0.f : ldg(D.ls_snap + j);
+    const float mean = x.mean, act = x.act;
+    float ls = x.ls;
     const float adv = P::round(fminf(qt1, qt2) - vv);                          // ref:583-587
     const float eadv = fminf(P::round(expf(P::round(D.beta * adv))), 100.f);   // ref:622
     const float gbc = eadv / fB;
@@ -449,11 +469,8 @@ __device__ __forceinline__ void loss_terms(const TrainerDesc &D, int net, int b,
       g = (w / fB) * (2.f * adv);
     dz3 = -g;  // adv = target_q - v
   } else {
-    const float nv = ldg(o + OUT_NV);
-    const float qv = ldg(o + (net == NET_Q1 ? OUT_Q1 : OUT_Q2));
-    const float rew = ldg(D.rd + (size_t)b * 2), done = ldg(D.rd + (size_t)b * 2 + 1);
-    const float target = rew + (1.f - done) * D.discount * nv;  // ref:604
-    const float diff = qv - target;
+    const float target = x.rew + (1.f - x.done) * D.discount * x.nv;  // ref:604
+    const float diff = x.qv - target;
     lterm = diff * diff;
     dz3 = P::round(diff / fB);  // 0.5 * 2 (q - t) / B
   }
@@ -500,7 +517,15 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   if (blk == 0 && tid == 0) Cp->ctr[1] = Cp->ctr[0] + 1;
   STAMP(1, 0);
 
-  // ---- request everything that does not depend on the loss ----
+  // ---- the loss inputs first: loads return in order, these must not queue behind the
+  // weight stream requested next (thread e -> row e / out_dim, output e % out_dim) ----
+  LossIn lin[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + 256 * u;
+    if (e < SLAB * N.out_dim) lin[u] = loss_inputs(D, net, slab * SLAB + e / N.out_dim, e % N.out_dim);
+  }
+  // ---- request everything else that does not depend on the loss ----
   uint4 w2t[K::NKC][TPH];
   const T *W2T = reinterpret_cast<const T *>(N.w2ct);
   const T *W3c = reinterpret_cast<const T *>(N.wc[2]);
@@ -527,13 +552,16 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
 
   // ---- per-row loss terms and d(loss)/d(out)  (ref:581-637) ----
   STAMP(1, 1);
-  for (int e = tid; e < SLAB * 32; e += 256) dz3[e] = 0.f, lterm[e] = 0.f, gstd[e] = 0.f;
-  __syncthreads();
-  for (int e = tid; e < SLAB * N.out_dim; e += 256) {
-    const int rr = e / N.out_dim, j = e - rr * N.out_dim;
-    float d3, lt, gs;
-    loss_terms<BF16>(D, net, slab * SLAB + rr, j, fB, d3, lt, gs);
-    dz3[rr * 32 + j] = d3, lterm[rr * 32 + j] = lt, gstd[rr * 32 + j] = gs;
+  // LDS layout [j][16 rows]: the dZ2 phase reads four rows per instruction
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + 256 * u;
+    if (e < SLAB * N.out_dim) {
+      const int rr = e / N.out_dim, j = e - rr * N.out_dim;
+      float d3, lt, gs;
+      loss_terms<BF16>(D, net, lin[u], fB, d3, lt, gs);
+      dz3[j * SLAB + rr] = d3, lterm[j * SLAB + rr] = lt, gstd[j * SLAB + rr] = gs;
+    }
   }
   __syncthreads();
   STAMP(1, 2);
@@ -541,21 +569,21 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   // per-slab partial sums in a fixed order (deterministic): rows first, then the 16 row sums
   if (tid < SLAB) {
     float s = 0.f;
-    for (int j = 0; j < N.out_dim; ++j) s += lterm[tid * 32 + j];
+    for (int j = 0; j < N.out_dim; ++j) s += lterm[j * SLAB + tid];
     rowsum[tid] = s;
   }
   if (half == 0 && net == NET_A && !D.deterministic && tid >= 64 && tid < 64 + D.A) {
     const int j = tid - 64;
     float s = 0.f;
 #pragma unroll
-    for (int rr = 0; rr < SLAB; ++rr) s += gstd[rr * 32 + j];
+    for (int rr = 0; rr < SLAB; ++rr) s += gstd[j * SLAB + rr];
     stg(D.lsp + (size_t)slab * D.A + j, s);
   }
   // d(out), feature-major, for the layer-3 weight gradient
   for (int e = tid; half == 0 && e < N.out_dim * SLAB; e += 256) {
     const int j = e / SLAB, rr = e - j * SLAB;
     stg(reinterpret_cast<T *>(D.dz3T) + (size_t)net * D.opmax * BP + fidx<P>(j, slab * SLAB + rr, nkb),
-        P::from_f32(dz3[rr * 32 + j]));
+        P::from_f32(dz3[j * SLAB + rr]));
   }
 
   // ---- dZ2 = (dZ3 W3) * relu'(h2)   (VALU: K = out_dim <= 32) ----
@@ -568,7 +596,11 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     for (int j = 0; j < 32; ++j) {
       if (j < N.out_dim) {
 #pragma unroll
-        for (int rr = 0; rr < SLAB; ++rr) s[rr] += dz3[rr * 32 + j] * w3v[j];
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float4 dv = *reinterpret_cast<const float4 *>(&dz3[j * SLAB + 4 * g4]);
+          s[4 * g4] += dv.x * w3v[j], s[4 * g4 + 1] += dv.y * w3v[j];
+          s[4 * g4 + 2] += dv.z * w3v[j], s[4 * g4 + 3] += dv.w * w3v[j];
+        }
       }
     }
 #pragma unroll
