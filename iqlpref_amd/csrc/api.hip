@@ -105,6 +105,7 @@ struct iqlhip_trainer {
   int n_items = 0;
 
   float *batch_rows = nullptr;  // [B][stride] staging for iqlhip_train_batch
+  int64_t call_id = 0;          // tags the batches prefetched during one run_steps call
   int64_t total_it = 0;
   double lr_q, lr_v, lr_a_base;
   // hipGraph of `graph_unroll` steps
@@ -285,6 +286,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   add((size_t)A * 4);
   const int stride = iqlhip_replay_row_stride(S, A);
   add((size_t)B * stride * 4);
+  add((size_t)B * stride * 4);  // stage_rows
   add(sizeof(DevArgs));
   add(sizeof(DevCtr));
   add(sizeof(TrainerDesc));
@@ -319,6 +321,12 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
       pad.net = -1;
       items.push_back(d < per_xcd[x].size() ? per_xcd[x][d] : pad);
     }
+  // the padding slots prefetch the next step's batch: number them
+  int n_pad = 0;
+  for (auto &it : items)
+    if (it.net < 0) it.o0 = n_pad++;
+  for (auto &it : items)
+    if (it.net < 0) it.i0 = n_pad;
   t->n_items = (int)items.size();
   add(items.size() * sizeof(UpdItem));
 
@@ -365,6 +373,9 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   D.lsp = carve<float>(p, (size_t)(B / 16) * A);
   D.ls_snap = carve<float>(p, (size_t)A);
   t->batch_rows = carve<float>(p, (size_t)B * stride);
+  D.stage_rows = carve<float>(p, (size_t)B * stride);
+  D.stage_stride = stride;
+  if (n_pad == 0 || getenv("IQLHIP_NO_PREFETCH")) D.stage_rows = nullptr;
   t->dargs = carve<DevArgs>(p, 1);
   t->dctr = carve<DevCtr>(p, 1);
   t->ddesc = carve<TrainerDesc>(p, 1);
@@ -504,8 +515,11 @@ static int enqueue_step(iqlhip_trainer *t, hipStream_t st) {
   return 0;
 }
 
-static int run_steps(iqlhip_trainer *t, const DevArgs &args, int64_t n_steps, int graph_unroll,
+static int run_steps(iqlhip_trainer *t, const DevArgs &args_in, int64_t n_steps, int graph_unroll,
                      hipStream_t st) {
+  DevArgs args = args_in;
+  args.n_steps = n_steps;
+  args.call_id = ++t->call_id;
   HIP_TRY(hipMemcpyAsync(t->dargs, &args, sizeof(DevArgs), hipMemcpyHostToDevice, st));
   int64_t done = 0;
   if (t->timing) {

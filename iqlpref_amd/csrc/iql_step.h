@@ -61,6 +61,8 @@ struct TrainerDesc {
   float *lossp;   // [4][nslab]   per-slab loss partial sums
   float *lsp;     // [nslab][A]   per-slab d(loss)/d(std) partial sums
   float *ls_snap; // [A] log_std as of the start of the step (written by k_forward's spare block)
+  float *stage_rows;  // [B][row_stride] next step's batch, or null (no idle work-groups)
+  int32_t stage_stride;
   int32_t opmax, xrows;
   unsigned long long *dbg;  // diagnostic stamps (IQL_STAMPS builds), else null
 };
@@ -76,6 +78,8 @@ struct DevArgs {
   float *losses_out;         // [n][3] or null
   int64_t base_step;         // total_it of the first step of this call
   double lr_q, lr_v, lr_a_base;
+  int64_t n_steps;           // steps of this call (bounds idx[] for the batch prefetch)
+  int64_t call_id;           // host counter: tags the prefetched batch with the call that made it
 };
 
 // Device-written counters / metrics.
@@ -89,12 +93,16 @@ struct DevCtr {
   double loss_sum[4];
   AdamCoef coef;   // written by a spare forward block for the step in flight
   int64_t coef_step;  // 1-based Adam step `coef` belongs to (= ctr[0] + 1 of that forward)
+  // batch prefetch: idle work-groups of k_update gather the NEXT step's replay rows into
+  // TrainerDesc::stage_rows; k_forward uses them when the tag matches its step and call
+  int64_t staged_step, staged_call;
 };
 
 // One work-group of k_update: everything it needs, flattened (no second,
 // dependent descriptor load; no runtime-indexed struct arrays -> no scratch).
 struct UpdItem {
-  int32_t net, layer;      // net < 0: padding slot of the XCD-major table
+  int32_t net, layer;      // net < 0: padding slot of the XCD-major table (o0 = its index among
+                           // the padding slots, i0 = their count: they prefetch the next batch)
   int32_t o0, i0;          // tile origin: out-features [o0, +64) x in-features [i0, +64)
   int32_t Odim, Idim;      // true extents of the weight matrix
   int32_t Opad, Kw;        // out-features padded to 16; K extent of the compute copy

@@ -335,16 +335,23 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   const int row = slab * SLAB + rr;
   constexpr int NXV = 8;  // k1pad <= 128 -> at most 8 elements per lane
   float xv[NXV], av[2], rdv = 0.f;
+  // rows already gathered by the previous k_update's idle work-groups?
+  const bool staged = D.stage_rows && Cp->staged_step == step && Cp->staged_call == A.call_id;
   auto issue = [&]() {
-    int64_t ix;
-    if (A.idx_mode == 1)
-      ix = ldg(A.idx + (size_t)(step - A.base_step) * D.B + row);
-    else if (A.idx_mode == 2)
-      ix = row;
-    else
-      ix = philox_index(D.seed, (uint64_t)step, (uint32_t)row, (uint64_t)A.n_rows);
-    ix = ix < 0 ? 0 : (ix >= A.n_rows ? A.n_rows - 1 : ix);
-    const float *src = A.rows + (size_t)ix * A.row_stride;
+    const float *src;
+    if (staged) {
+      src = D.stage_rows + (size_t)row * D.stage_stride;
+    } else {
+      int64_t ix;
+      if (A.idx_mode == 1)
+        ix = ldg(A.idx + (size_t)(step - A.base_step) * D.B + row);
+      else if (A.idx_mode == 2)
+        ix = row;
+      else
+        ix = philox_index(D.seed, (uint64_t)step, (uint32_t)row, (uint64_t)A.n_rows);
+      ix = ix < 0 ? 0 : (ix >= A.n_rows ? A.n_rows - 1 : ix);
+      src = A.rows + (size_t)ix * A.row_stride;
+    }
 #pragma unroll
     for (int j = 0; j < NXV; ++j) {
       const int c = l16 + 16 * j;
@@ -785,13 +792,38 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
         stg(lo, vl), stg(lo + 1, ql), stg(lo + 2, al);
       }
       Cp->ctr[0] = t1;
+      const bool stage_ok = D.stage_rows && A.row_stride == D.stage_stride &&
+                            (A.idx_mode == 0 || (A.idx_mode == 1 && t1 - A.base_step < A.n_steps));
+      Cp->staged_step = stage_ok ? t1 : -1;
+      Cp->staged_call = A.call_id;
     }
     STAMP(2, 4);
     return;
   }
 
   const UpdItem it = items[blk];
-  if (it.net < 0) return;  // padding slot of the XCD-major item table
+  // the batch of step t1 (0-based: the next forward) can be fetched now iff its indices are known
+  const bool can_stage = D.stage_rows && A.row_stride == D.stage_stride &&
+                         (A.idx_mode == 0 || (A.idx_mode == 1 && t1 - A.base_step < A.n_steps));
+  if (it.net < 0) {
+    // padding slot of the XCD-major item table: gather the next step's replay rows while the
+    // tiles work (random HBM rows + TLB misses leave the next k_forward's critical path)
+    if (can_stage) {
+      const int rr = tid >> 4, l16 = tid & 15;
+      for (int row = it.o0 * 16 + rr; row < B; row += it.i0 * 16) {
+        int64_t ix;
+        if (A.idx_mode == 1)
+          ix = ldg(A.idx + (size_t)(t1 - A.base_step) * B + row);
+        else
+          ix = philox_index(D.seed, (uint64_t)t1, (uint32_t)row, (uint64_t)A.n_rows);
+        ix = ix < 0 ? 0 : (ix >= A.n_rows ? A.n_rows - 1 : ix);
+        const float *src = A.rows + (size_t)ix * A.row_stride;
+        float *dst = D.stage_rows + (size_t)row * D.stage_stride;
+        for (int c = l16; c < D.stage_stride; c += 16) stg(dst + c, ldg(src + c));
+      }
+    }
+    return;
+  }
   const int L = it.layer;
   const int Odim = it.Odim, Idim = it.Idim, Kw = it.Kw, Opad = it.Opad;
   const int Ipad = round_up(Idim, 16);
