@@ -93,16 +93,22 @@ typedef struct {
   double adam_beta1, adam_beta2, adam_eps;
   int64_t cosine_t_max;  /* CosineAnnealingLR T_max = max_steps (ref:571)         */
   uint64_t seed;         /* Philox key for on-device indices and dropout          */
+  int32_t n_critics;     /* 0 or 2: TwinQ (ref:517-533); 3..8: E-way critic ensemble,
+                            the same MLP E times, q_target = min over E, q_loss =
+                            sum(mse)/E (ref:606 generalised; SURVEY 8 "config 5")    */
+  int32_t reserved;
 } iqlhip_trainer_config;
 
 /* Number of fp32 elements of the arenas (n_params, n_target: they include the
  * alignment padding, every tensor starts on a 128-byte line; padding elements
  * are never read or written) and the element offset of every tensor in the
- * parameter arena.  Order of the 25 offsets: for net in (q1, q2, v, actor):
- * W1[H][in] b1[H] W2[H][H] b2[H] W3[out][H] b3[out]; then actor log_std[A]
- * (offset -1 when deterministic).  Torch [out][in] row-major layouts.
- * The target arena uses the q1,q2 part of the same layout.                  */
-#define IQLHIP_N_TENSORS 25
+ * parameter arena.  Order of the 6(E+2)+1 offsets (25 for TwinQ): for net in
+ * (q1, .., qE, v, actor): W1[H][in] b1[H] W2[H][H] b2[H] W3[out][H] b3[out];
+ * then actor log_std[A] (offset -1 when deterministic); unused slots are -1.
+ * Torch [out][in] row-major layouts.  The target arena uses the q1..qE part of
+ * the same layout.                                                           */
+#define IQLHIP_MAX_CRITICS 8
+#define IQLHIP_N_TENSORS (6 * (IQLHIP_MAX_CRITICS + 2) + 1)
 int iqlhip_arena_layout(const iqlhip_trainer_config *cfg, int64_t offsets[IQLHIP_N_TENSORS],
                         int64_t *n_params, int64_t *n_target);
 
@@ -152,10 +158,10 @@ int iqlhip_train_batch(iqlhip_trainer *t, const float *s, const float *a, const 
                        float *losses_out, void *stream);
 
 /* Forward passes on the live weights (ref:452-543), n rows (any n >= 1):
- *   which = 0: q1,q2 -> out[n][2]   (needs a)
+ *   which = 0: q1..qE -> out[n][E]   (needs a; E = 2 for TwinQ)
  *   which = 1: v     -> out[n]
  *   which = 2: actor mean (tanh)  -> out[n][A]   (eval mode: no dropout)
- *   which = 3: q_target1, q_target2 -> out[n][2]   (needs a)                */
+ *   which = 3: q_target1..E -> out[n][E]   (needs a)                        */
 int iqlhip_forward(iqlhip_trainer *t, int32_t which, const float *s, const float *a,
                    int64_t n, float *out, void *stream);
 

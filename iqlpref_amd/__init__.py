@@ -5,7 +5,7 @@ surface on top of libiqlhip.so (hand-written HIP for gfx950)."""
 from . import _lib  # noqa: F401
 from .iql import (  # noqa: F401
     EXP_ADV_MAX, LOG_STD_MAX, LOG_STD_MIN, MLP, DeterministicPolicy, GaussianPolicy,
-    ImplicitQLearning, ReplayBuffer, Squeeze, TrainConfig, TwinQ, ValueFunction,
+    EnsembleQ, ImplicitQLearning, ReplayBuffer, Squeeze, TrainConfig, TwinQ, ValueFunction,
     asymmetric_l2_loss, compute_mean_std, load_config, mlp_forward_f32, normalize_states,
     set_seed, soft_update)
 from .relabel import (  # noqa: F401,E402

@@ -12,9 +12,10 @@ LIB_PATH = os.environ.get("IQLHIP_LIB") or os.path.join(HERE, "libiqlhip.so")
 
 PREC_FP32 = 0
 PREC_BF16 = 1
-N_TENSORS = 25
+MAX_CRITICS = 8
+N_TENSORS = 6 * (MAX_CRITICS + 2) + 1
 MLP_MAX_LAYERS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ERR_INVALID = -1
 ERR_HIP = -2
@@ -37,7 +38,8 @@ class TrainerConfig(C.Structure):
                 ("lr_q", C.c_double), ("lr_v", C.c_double), ("lr_actor", C.c_double),
                 ("adam_beta1", C.c_double), ("adam_beta2", C.c_double),
                 ("adam_eps", C.c_double),
-                ("cosine_t_max", C.c_int64), ("seed", C.c_uint64)]
+                ("cosine_t_max", C.c_int64), ("seed", C.c_uint64),
+                ("n_critics", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Arenas(C.Structure):

@@ -63,7 +63,7 @@ static int fail(int code, const char *fmt, ...) {
   } while (0)
 
 extern "C" const char *iqlhip_last_error(void) { return g_err; }
-extern "C" int iqlhip_abi_version(void) { return 1; }
+extern "C" int iqlhip_abi_version(void) { return 2; }
 
 // ------------------------------------------------------------------ replay --
 extern "C" int32_t iqlhip_replay_row_stride(int32_t S, int32_t A) { return round_up(2 * S + A + 2, 4); }
@@ -120,8 +120,15 @@ struct iqlhip_trainer {
   int64_t t_n = 0;
 };
 
+static_assert(MAX_CRITICS == IQLHIP_MAX_CRITICS, "iql_step.h and iqlhip.h disagree");
+static_assert(IQLHIP_N_TENSORS == 6 * MAX_TRAIN + 1, "offset table size");
+// number of critics: 0 in the config means the reference's TwinQ
+static int n_critics(const iqlhip_trainer_config &c) { return c.n_critics > 0 ? c.n_critics : 2; }
+
 static int check_cfg(const iqlhip_trainer_config *c) {
   if (!c) return fail(IQLHIP_ERR_INVALID, "null config");
+  if (c->n_critics < 0 || c->n_critics == 1 || c->n_critics > MAX_CRITICS)
+    return fail(IQLHIP_ERR_UNSUPPORTED, "n_critics %d: 0 (= 2) or 2..%d", c->n_critics, MAX_CRITICS);
   if (c->state_dim <= 0 || c->action_dim <= 0) return fail(IQLHIP_ERR_INVALID, "bad dims");
   if (c->hidden_dim != 64 && c->hidden_dim != 128 && c->hidden_dim != 256)
     return fail(IQLHIP_ERR_UNSUPPORTED, "hidden_dim %d: kernels are built for 64, 128 and 256", c->hidden_dim);
@@ -129,7 +136,7 @@ static int check_cfg(const iqlhip_trainer_config *c) {
     return fail(IQLHIP_ERR_UNSUPPORTED, "batch_size %d: must be a positive multiple of 16", c->batch_size);
   if (c->action_dim > 32) return fail(IQLHIP_ERR_UNSUPPORTED, "action_dim %d > 32", c->action_dim);
   if (c->state_dim + c->action_dim > 128) return fail(IQLHIP_ERR_UNSUPPORTED, "state_dim+action_dim > 128");
-  if ((c->batch_size / 16) * (4 + (c->deterministic ? 0 : c->action_dim)) > 1020)
+  if ((c->batch_size / 16) * (n_critics(*c) + 2 + (c->deterministic ? 0 : c->action_dim)) > 8000)
     return fail(IQLHIP_ERR_UNSUPPORTED, "batch_size %d too large for action_dim %d", c->batch_size,
                 c->action_dim);
   if (c->precision != IQLHIP_PREC_FP32 && c->precision != IQLHIP_PREC_BF16)
@@ -145,8 +152,9 @@ struct Layout {
   int64_t true_params, true_target;  // trained scalars (SURVEY 8d byte model)
 };
 static void net_dims(const iqlhip_trainer_config &c, int net, int *in, int *out) {
-  *in = (net == NET_Q1 || net == NET_Q2) ? c.state_dim + c.action_dim : c.state_dim;
-  *out = (net == NET_A) ? c.action_dim : 1;
+  const int E = n_critics(c);
+  *in = net < E ? c.state_dim + c.action_dim : c.state_dim;
+  *out = (net == E + 1) ? c.action_dim : 1;
 }
 static Layout make_layout(const iqlhip_trainer_config &c) {
   // every tensor starts on a 128-byte line: rows of the H-wide matrices and the flat layer-1
@@ -155,7 +163,9 @@ static Layout make_layout(const iqlhip_trainer_config &c) {
   Layout L;
   int64_t o = 0, cnt = 0;
   const int H = c.hidden_dim;
-  for (int n = 0; n < N_TRAIN; ++n) {
+  const int E = n_critics(c), ntrain = E + 2;
+  for (int k = 0; k < IQLHIP_N_TENSORS; ++k) L.off[k] = -1;
+  for (int n = 0; n < ntrain; ++n) {
     int in, out;
     net_dims(c, n, &in, &out);
     const int64_t sz[6] = {(int64_t)H * in, H, (int64_t)H * H, H, (int64_t)out * H, out};
@@ -165,13 +175,13 @@ static Layout make_layout(const iqlhip_trainer_config &c) {
       o += sz[k];
       cnt += sz[k];
     }
-    if (n == NET_Q2) L.n_target = o, L.true_target = cnt;
+    if (n == E - 1) L.n_target = o, L.true_target = cnt;
   }
   if (c.deterministic) {
-    L.off[24] = -1;
+    L.off[ntrain * 6] = -1;
   } else {
     o = (o + ALIGN - 1) / ALIGN * ALIGN;
-    L.off[24] = o;
+    L.off[ntrain * 6] = o;
     o += c.action_dim;
     cnt += c.action_dim;
   }
@@ -197,10 +207,11 @@ extern "C" int iqlhip_step_cost(const iqlhip_trainer_config *cfg, double *bytes,
   // gather + (read p,g,m,v; write g,p,m,v) per trained parameter + target r/w
   if (bytes) *bytes = 4.0 * B * (2 * S + A + 2) + 32.0 * (double)L.true_params + 8.0 * (double)L.true_target;
   if (flops) {
+    const double E = n_critics(*cfg);
     const double wv = S * H + H * H + H, wq = (S + A) * H + H * H + H, wa = S * H + H * H + H * A;
-    const double fwd = 2 * wv + 4 * wq + wa;                     // V twice, target+online twin Q, actor
-    const double dw = wv + 2 * wq + wa;                          // weight gradients
-    const double dx = (H * H + H) * 3 + (H * H + H * A);         // input gradients of layers 3, 2
+    const double fwd = 2 * wv + 2 * E * wq + wa;                 // V twice, target+online critics, actor
+    const double dw = wv + E * wq + wa;                          // weight gradients
+    const double dx = (H * H + H) * (E + 1) + (H * H + H * A);   // input gradients of layers 3, 2
     *flops = 2.0 * B * (fwd + dw + dx);
   }
   return 0;
@@ -231,7 +242,11 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   TrainerDesc &D = t->D;
   memset(&D, 0, sizeof(D));
   D.S = S, D.A = A, D.H = H, D.B = B, D.BP = round_up(B, 32);
-  D.OUTW = round_up(OUT_MEAN + A, 4);
+  const int E = n_critics(*cfg), NT = E + 2, NF = 2 * E + 3;
+  D.E = E, D.ntrain = NT, D.nfwd = NF, D.net_v = E, D.net_a = E + 1;
+  D.out_v = E, D.out_qt = E + 1, D.out_nv = 2 * E + 1, D.out_mean = 2 * E + 2;
+  D.two_over_B = 2.0f / (float)B, D.inv_E = 1.0f / (float)E;
+  D.OUTW = round_up(D.out_mean + A, 4);
   D.deterministic = cfg->deterministic;
   D.has_dropout = cfg->dropout_p > 0.f;
   D.discount = cfg->discount, D.tau = cfg->tau, D.beta = cfg->beta, D.iql_tau = cfg->iql_tau;
@@ -253,19 +268,19 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   D.seed = cfg->seed;
   D.params = ar->params, D.exp_avg = ar->exp_avg, D.exp_avg_sq = ar->exp_avg_sq;
   D.target = ar->target, D.grads = ar->grads;
-  D.off_log_std = L.off[24];
+  D.off_log_std = L.off[NT * 6];
   D.opmax = round_up(A, 16);
   D.xrows = round_up(S + A, 64);
   D.k1max = round_up(S + A, KM);
   // ---- workspace ----
   size_t total = 0;
   auto add = [&](size_t bytes) { total += (bytes + 255) / 256 * 256; };
-  int k1pad[N_TRAIN], outpad[N_TRAIN], indim[N_TRAIN], outdim[N_TRAIN];
-  for (int n = 0; n < N_TRAIN; ++n) {
+  int k1pad[MAX_TRAIN], outpad[MAX_TRAIN], indim[MAX_TRAIN], outdim[MAX_TRAIN];
+  for (int n = 0; n < NT; ++n) {
     net_dims(*cfg, n, &indim[n], &outdim[n]);
     k1pad[n] = round_up(indim[n], KM);
     outpad[n] = round_up(outdim[n], 16);
-    const int copies = (n <= NET_Q2) ? 2 : 1;  // + target copies
+    const int copies = (n < E) ? 2 : 1;  // + target copies
     for (int c = 0; c < copies; ++c) {
       add((size_t)H * k1pad[n] * es);
       add((size_t)H * H * es);
@@ -276,12 +291,12 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   add((size_t)D.xrows * D.BP * es);
   add((size_t)B * 2 * 4);
   add((size_t)B * A * 4);
-  add((size_t)4 * 2 * H * D.BP * es);
-  add((size_t)4 * H * D.BP * es);
-  add((size_t)4 * H * D.BP * es);
-  add((size_t)4 * D.opmax * D.BP * es);
+  add((size_t)NT * 2 * H * D.BP * es);
+  add((size_t)NT * H * D.BP * es);
+  add((size_t)NT * H * D.BP * es);
+  add((size_t)NT * D.opmax * D.BP * es);
   add((size_t)B * D.OUTW * 4);
-  add((size_t)4 * (B / 16) * 4);
+  add((size_t)NT * (B / 16) * 4);
   add((size_t)(B / 16) * A * 4);
   add((size_t)A * 4);
   const int stride = iqlhip_replay_row_stride(S, A);
@@ -296,14 +311,14 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   // dZ^T / activation panels they share are fetched into those two L2s only.
   // (pointers are filled in after the workspace has been carved)
   std::vector<UpdItem> per_xcd[8];
-  for (int n = 0; n < N_TRAIN; ++n) {
+  for (int n = 0; n < NT; ++n) {
     // layer 2 (the H x H matrix, 32 tiles at H = 256) fills XCD 2n: every dZ^T / activation
     // panel of that GEMM is then fetched into ONE L2; layers 1 and 3 go to XCD 2n+1
     auto put = [&](int layer, int o0, int i0) {
       UpdItem it;
       memset(&it, 0, sizeof(it));
       it.net = n, it.layer = layer, it.o0 = o0, it.i0 = i0;
-      per_xcd[2 * n + (layer == 1 ? 0 : 1)].push_back(it);
+      per_xcd[(2 * n + (layer == 1 ? 0 : 1)) & 7].push_back(it);
     };
     for (int o0 = 0; o0 < H; o0 += 64)
       for (int i0 = 0; i0 < H; i0 += 32) put(1, o0, i0);
@@ -341,10 +356,10 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
     return fail(IQLHIP_ERR_HIP, "hipMemset failed");
   }
   char *p = reinterpret_cast<char *>(t->ws);
-  for (int n = 0; n < N_TRAIN; ++n) {
+  for (int n = 0; n < NT; ++n) {
     TrainNet &N = D.net[n];
     N.in_dim = indim[n], N.k1pad = k1pad[n], N.out_dim = outdim[n], N.out_pad = outpad[n];
-    N.has_target = n <= NET_Q2;
+    N.has_target = n < E;
     for (int k = 0; k < 3; ++k) {
       N.off_w[k] = L.off[n * 6 + 2 * k];
       N.off_b[k] = L.off[n * 6 + 2 * k + 1];
@@ -364,12 +379,12 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   D.xT = carve<char>(p, (size_t)D.xrows * D.BP * es);
   D.rd = carve<float>(p, (size_t)B * 2);
   D.actf = carve<float>(p, (size_t)B * A);
-  D.hT = carve<char>(p, (size_t)4 * 2 * H * D.BP * es);
-  D.dz1T = carve<char>(p, (size_t)4 * H * D.BP * es);
-  D.dz2T = carve<char>(p, (size_t)4 * H * D.BP * es);
-  D.dz3T = carve<char>(p, (size_t)4 * D.opmax * D.BP * es);
+  D.hT = carve<char>(p, (size_t)NT * 2 * H * D.BP * es);
+  D.dz1T = carve<char>(p, (size_t)NT * H * D.BP * es);
+  D.dz2T = carve<char>(p, (size_t)NT * H * D.BP * es);
+  D.dz3T = carve<char>(p, (size_t)NT * D.opmax * D.BP * es);
   D.outs = carve<float>(p, (size_t)B * D.OUTW);
-  D.lossp = carve<float>(p, (size_t)4 * (B / 16));
+  D.lossp = carve<float>(p, (size_t)NT * (B / 16));
   D.lsp = carve<float>(p, (size_t)(B / 16) * A);
   D.ls_snap = carve<float>(p, (size_t)A);
   t->batch_rows = carve<float>(p, (size_t)B * stride);
@@ -390,7 +405,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
     it.Opad = (L == 2) ? N.out_pad : H;
     it.Kw = (L == 0) ? N.k1pad : H;
     it.has_target = N.has_target;
-    it.group = it.net == NET_V ? 1 : (it.net == NET_A ? 2 : 0);
+    it.group = it.net == D.net_v ? 1 : (it.net == D.net_a ? 2 : 0);
     it.off_w = N.off_w[L], it.off_b = N.off_b[L], it.toff_w = N.toff_w[L], it.toff_b = N.toff_b[L];
 
     it.wc = N.wc[L], it.tc = N.has_target ? N.tc[L] : nullptr, it.w2ct = (L == 1) ? N.w2ct : nullptr;
@@ -419,17 +434,16 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
     F.in_off = in_off, F.in_dim = N.in_dim, F.k1pad = N.k1pad;
     F.out_dim = N.out_dim, F.out_pad = N.out_pad, F.out_col = out_col;
     F.train_slot = slot;
-    F.tanh_out = net == NET_A;
-    F.dropout = (net == NET_A) && D.has_dropout;
-    F.stage = f == FWD_Q1;
+    F.tanh_out = net == D.net_a;
+    F.dropout = (net == D.net_a) && D.has_dropout;
+    F.stage = f == 0;
   };
-  mk(FWD_Q1, NET_Q1, false, 0, OUT_Q1, NET_Q1);
-  mk(FWD_Q2, NET_Q2, false, 0, OUT_Q2, NET_Q2);
-  mk(FWD_V, NET_V, false, 0, OUT_V, NET_V);
-  mk(FWD_A, NET_A, false, 0, OUT_MEAN, NET_A);
-  mk(FWD_QT1, NET_Q1, true, 0, OUT_QT1, -1);
-  mk(FWD_QT2, NET_Q2, true, 0, OUT_QT2, -1);
-  mk(FWD_NV, NET_V, false, S + A + 2, OUT_NV, -1);
+  // evaluation order: q_e, v, actor, target q_e, next_v (iql_step.h)
+  for (int e = 0; e < E; ++e) mk(e, e, false, 0, e, e);
+  mk(E, D.net_v, false, 0, D.out_v, D.net_v);
+  mk(E + 1, D.net_a, false, 0, D.out_mean, D.net_a);
+  for (int e = 0; e < E; ++e) mk(E + 2 + e, e, true, 0, D.out_qt + e, -1);
+  mk(2 * E + 2, D.net_v, false, S + A + 2, D.out_nv, -1);
 
   if (hipMemcpy(t->ddesc, &t->D, sizeof(TrainerDesc), hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipFree(t->ws);
@@ -620,27 +634,28 @@ extern "C" int iqlhip_forward(iqlhip_trainer *t, int32_t which, const float *s, 
   if (n <= 0) return fail(IQLHIP_ERR_INVALID, "n must be positive");
   if ((which == 0 || which == 3) && !a) return fail(IQLHIP_ERR_INVALID, "Q forward needs actions");
   hipStream_t st = (hipStream_t)stream;
+  const int E = t->D.E;
   FwdNet N;
   switch (which) {
-    case 0:  // q1, q2 -> out[n][2]
-      N = t->D.fwd[FWD_Q1], N.out_col = 0, N.train_slot = -1, N.stage = 0;
-      HIP_TRY(launch_infer(t->bf16, t->D, t->ddesc, N, s, a, n, out, 2, st));
-      N = t->D.fwd[FWD_Q2], N.out_col = 1, N.train_slot = -1, N.stage = 0;
-      HIP_TRY(launch_infer(t->bf16, t->D, t->ddesc, N, s, a, n, out, 2, st));
+    case 0:  // q_1 .. q_E -> out[n][E]
+      for (int e = 0; e < E; ++e) {
+        N = t->D.fwd[e], N.out_col = e, N.train_slot = -1, N.stage = 0;
+        HIP_TRY(launch_infer(t->bf16, t->D, t->ddesc, N, s, a, n, out, E, st));
+      }
       return 0;
     case 1:
-      N = t->D.fwd[FWD_V], N.out_col = 0, N.train_slot = -1;
+      N = t->D.fwd[E], N.out_col = 0, N.train_slot = -1;
       HIP_TRY(launch_infer(t->bf16, t->D, t->ddesc, N, s, a, n, out, 1, st));
       return 0;
     case 2:  // eval-mode actor: no dropout (ref:299 actor.eval())
-      N = t->D.fwd[FWD_A], N.out_col = 0, N.train_slot = -1, N.dropout = 0;
+      N = t->D.fwd[E + 1], N.out_col = 0, N.train_slot = -1, N.dropout = 0;
       HIP_TRY(launch_infer(t->bf16, t->D, t->ddesc, N, s, a, n, out, t->cfg.action_dim, st));
       return 0;
-    case 3:  // target twin Q -> out[n][2]
-      N = t->D.fwd[FWD_QT1], N.out_col = 0;
-      HIP_TRY(launch_infer(t->bf16, t->D, t->ddesc, N, s, a, n, out, 2, st));
-      N = t->D.fwd[FWD_QT2], N.out_col = 1;
-      HIP_TRY(launch_infer(t->bf16, t->D, t->ddesc, N, s, a, n, out, 2, st));
+    case 3:  // target critics -> out[n][E]
+      for (int e = 0; e < E; ++e) {
+        N = t->D.fwd[E + 2 + e], N.out_col = e;
+        HIP_TRY(launch_infer(t->bf16, t->D, t->ddesc, N, s, a, n, out, E, st));
+      }
       return 0;
     default:
       return fail(IQLHIP_ERR_INVALID, "which must be 0..3");

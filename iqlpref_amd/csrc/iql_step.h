@@ -4,12 +4,15 @@
 
 namespace iqlhip {
 
-// The four trained networks and the seven forward evaluations of one step.
-enum { NET_Q1 = 0, NET_Q2 = 1, NET_V = 2, NET_A = 3, N_TRAIN = 4 };
-enum { FWD_Q1 = 0, FWD_Q2, FWD_V, FWD_A, FWD_QT1, FWD_QT2, FWD_NV, N_FWD };
-
-// columns of the per-row forward outputs  outs[B][OUTW]
-enum { OUT_Q1 = 0, OUT_Q2, OUT_V, OUT_QT1, OUT_QT2, OUT_NV, OUT_MEAN };
+// E critics (TwinQ: E = 2; SURVEY 8 "config 5": the E-way critic ensemble), V and the actor are
+// trained; one step evaluates the E critics, V(s), the actor, the E target critics and V(s').
+//   trained nets : critic e = e, V = E, actor = E + 1                      (E + 2)
+//   evaluations  : q_e = e, v = E, actor = E + 1, qt_e = E + 2 + e, next_v = 2E + 2   (2E + 3)
+//   columns of the per-row forward outputs outs[B][OUTW]:
+//                  q_e = e, v = E, qt_e = E + 1 + e, next_v = 2E + 1, mean_j = 2E + 2 + j
+constexpr int MAX_CRITICS = 8;
+constexpr int MAX_TRAIN = MAX_CRITICS + 2;
+constexpr int MAX_FWD = 2 * MAX_CRITICS + 3;
 
 struct FwdNet {
   const void *w1c, *w2c, *w3c;  // compute-precision copies [H][k1pad] [H][H] [out_pad][H]
@@ -37,6 +40,9 @@ struct TrainNet {
 
 struct TrainerDesc {
   int32_t S, A, H, B, BP, OUTW, k1max;  // BP: batch leading dimension (B padded to 32)
+  int32_t E, ntrain, nfwd, net_v, net_a; // critics; E + 2; 2E + 3; E; E + 1
+  int32_t out_v, out_qt, out_nv, out_mean;  // column bases in outs[][]
+  float two_over_B, inv_E;               // mse backward: (2/B) * (q - t) * (1/E)   (ref:606)
   int32_t deterministic, has_dropout;
   float discount, tau, beta, iql_tau;
   float drop_scale;      // 1/(1-p), bf16-rounded in bf16 mode (ATen _dropout_impl)
@@ -47,18 +53,18 @@ struct TrainerDesc {
   // arenas
   float *params, *exp_avg, *exp_avg_sq, *target, *grads;
   int64_t off_log_std;
-  FwdNet fwd[N_FWD];
-  TrainNet net[N_TRAIN];
+  FwdNet fwd[MAX_FWD];
+  TrainNet net[MAX_TRAIN];
   // workspace (T = compute type)
   void *xT;       // [xrows][B]   layer-1 input (s|a), feature-major
   float *rd;      // [B][2]       reward, done
   float *actf;    // [B][A]       actions (fp32, actor loss)
-  void *hT;       // [4][2][H][B] hidden activations (post ReLU / dropout)
-  void *dz1T;     // [4][H][B]
-  void *dz2T;     // [4][H][B]
-  void *dz3T;     // [4][opmax][B]
+  void *hT;       // [ntrain][2][H][B] hidden activations (post ReLU / dropout)
+  void *dz1T;     // [ntrain][H][B]
+  void *dz2T;     // [ntrain][H][B]
+  void *dz3T;     // [ntrain][opmax][B]
   float *outs;    // [B][OUTW]
-  float *lossp;   // [4][nslab]   per-slab loss partial sums
+  float *lossp;   // [ntrain][nslab]   per-slab loss partial sums
   float *lsp;     // [nslab][A]   per-slab d(loss)/d(std) partial sums
   float *ls_snap; // [A] log_std as of the start of the step (written by k_forward's spare block)
   float *stage_rows;  // [B][row_stride] next step's batch, or null (no idle work-groups)

@@ -38,7 +38,7 @@ constexpr int SLAB = 16;  // batch rows per work-group (one MFMA M tile)
 #ifdef IQL_STAMPS
 #define STAMP(kern, slot)                                                                   \
   do {                                                                                      \
-    if (D.dbg && threadIdx.x == 0) {                                                        \
+    if (D.dbg && threadIdx.x == 0 && blockIdx.x < 512) {                                                      \
       unsigned long long *d_ = D.dbg + (((size_t)(kern) * 512 + blockIdx.x) * 8 + (slot)) * 2; \
       d_[0] = wall_clock64();                                                               \
       d_[1] = clock64();                                                                    \
@@ -312,10 +312,14 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   using P = Prec<BF16>;
   using T = typename P::T;
   // blocks are dealt round-robin over the 8 XCDs: keep all slabs of one network on one
-  // XCD so its weights are fetched into that L2 once (speed only, never correctness)
-  const int fnet = blockIdx.x & 7, slab = blockIdx.x >> 3;
+  // XCD so its weights are fetched into that L2 once (speed only, never correctness).
+  // Job j (evaluation j < nfwd, or the spare job nfwd) lives on XCD j & 7, round j >> 3.
   const TrainerDesc &D = *Dp;
-  if (fnet >= N_FWD) {
+  const int nsl_ = D.B / SLAB;
+  const int idx_ = blockIdx.x >> 3;
+  const int fnet = (idx_ / nsl_) * 8 + (blockIdx.x & 7), slab = idx_ % nsl_;
+  if (fnet > D.nfwd) return;
+  if (fnet == D.nfwd) {
     // spare XCD slot: one thread prepares this step's Adam coefficients for k_update
     if (slab == 0 && threadIdx.x == 0) {
       write_adam_coef(D, *Ap, Cp->ctr[0] + 1, const_cast<AdamCoef *>(&Cp->coef));
@@ -417,22 +421,27 @@ __global__ __launch_bounds__(256) void k_infer(const TrainerDesc *__restrict__ D
 // identical instruction sequence, identical bits.
 // ------------------------------------------------------------------------
 struct LossIn {
-  float qt1, qt2, vv, mean, act, ls, nv, qv, rew, done;
+  float qtmin, vv, mean, act, ls, nv, qv, rew, done;  // qtmin: min over the E target critics
 };
 
 // the loads of loss_terms, separated so that k_backward can issue them before its weight stream
 __device__ __forceinline__ LossIn loss_inputs(const TrainerDesc &D, int net, int b, int j) {
   const float *o = D.outs + (size_t)b * D.OUTW;
   LossIn x;
-  x.qt1 = ldg(o + OUT_QT1), x.qt2 = ldg(o + OUT_QT2), x.vv = ldg(o + OUT_V);
-  x.mean = x.act = x.ls = x.nv = x.qv = x.rew = x.done = 0.f;
-  if (net == NET_A) {
-    x.mean = ldg(o + OUT_MEAN + j);
-    x.act = ldg(D.actf + (size_t)b * D.A + j);
-    x.ls = D.deterministic ? 0.f : ldg(D.ls_snap + j);
-  } else if (net != NET_V) {
-    x.nv = ldg(o + OUT_NV);
-    x.qv = ldg(o + (net == NET_Q1 ? OUT_Q1 : OUT_Q2));
+  x.qtmin = x.vv = x.mean = x.act = x.ls = x.nv = x.qv = x.rew = x.done = 0.f;
+  if (net >= D.net_v) {
+    // TwinQ.forward = min(q1, q2) of the target critics (ref:531-533, 583-584); min over all E
+    x.qtmin = ldg(o + D.out_qt);
+    for (int e = 1; e < D.E; ++e) x.qtmin = fminf(x.qtmin, ldg(o + D.out_qt + e));
+    x.vv = ldg(o + D.out_v);
+    if (net == D.net_a) {
+      x.mean = ldg(o + D.out_mean + j);
+      x.act = ldg(D.actf + (size_t)b * D.A + j);
+      x.ls = D.deterministic ? 0.f : ldg(D.ls_snap + j);
+    }
+  } else {
+    x.nv = ldg(o + D.out_nv);
+    x.qv = ldg(o + net);
     x.rew = ldg(D.rd + (size_t)b * 2), x.done = ldg(D.rd + (size_t)b * 2 + 1);
   }
   return x;
@@ -442,12 +451,12 @@ template <bool BF16>
 __device__ __forceinline__ void loss_terms(const TrainerDesc &D, int net, const LossIn &x, float fB,
                                            float &dz3, float &lterm, float &gstd) {
   using P = Prec<BF16>;
-  const float qt1 = x.qt1, qt2 = x.qt2, vv = x.vv;
+  const float qtm = x.qtmin, vv = x.vv;
   gstd = 0.f;
-  if (net == NET_A) {
+  if (net == D.net_a) {
     const float mean = x.mean, act = x.act;
     float ls = x.ls;
-    const float adv = P::round(fminf(qt1, qt2) - vv);                          // ref:583-587
+    const float adv = P::round(qtm - vv);                                      // ref:583-587
     const float eadv = fminf(P::round(expf(P::round(D.beta * adv))), 100.f);   // ref:622
     const float gbc = eadv / fB;
     float gm, bc;
@@ -465,8 +474,8 @@ __device__ __forceinline__ void loss_terms(const TrainerDesc &D, int net, const 
     }
     lterm = eadv * bc;
     dz3 = P::round(gm * (1.f - mean * mean));  // tanh backward
-  } else if (net == NET_V) {
-    const float adv = P::round(fminf(qt1, qt2) - vv);
+  } else if (net == D.net_v) {
+    const float adv = P::round(qtm - vv);
     const float w = fabsf(D.iql_tau - (adv < 0.f ? 1.f : 0.f));  // ref:404-405
     lterm = w * P::round(adv * adv);
     float g;
@@ -479,7 +488,9 @@ __device__ __forceinline__ void loss_terms(const TrainerDesc &D, int net, const 
     const float target = x.rew + (1.f - x.done) * D.discount * x.nv;  // ref:604
     const float diff = x.qv - target;
     lterm = diff * diff;
-    dz3 = P::round(diff / fB);  // 0.5 * 2 (q - t) / B
+    // q_loss = sum_e mse(q_e, t) / E (ref:606): the division hands 1/E to each mse term, whose
+    // backward is (2/B) * (q - t) * grad_out; for E = 2 and B a power of two = (q - t) / B
+    dz3 = P::round((D.two_over_B * diff) * D.inv_E);
   }
 }
 
@@ -498,14 +509,18 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   // the cheap loss / dZ2 phase, work-group 0 stores it.
   constexpr int SPLIT = K::TPW >= 2 ? 2 : 1;
   constexpr int TPH = K::TPW / SPLIT;  // n-tiles per wave in the dZ1 GEMM
-  const int xcd = blk & 7, net = xcd >> 1;
-  const int rest = blk >> 3;
-  // SPLIT == 2: XCD 2n runs half 0 of every slab of net n, XCD 2n+1 half 1, so each L2
-  // fetches only the half of W2^T its work-groups stream
-  const int half = SPLIT == 2 ? (xcd & 1) : 0;
-  const int slab = SPLIT == 2 ? rest : ((rest << 1) | (xcd & 1));
+  // Job j = 2 net + sub lives on XCD j & 7, round j >> 3 (E = 2: XCD x serves network x / 2).
+  // SPLIT == 2: sub = which half of W2^T (each L2 fetches only the half its work-groups
+  // stream); SPLIT == 1: sub = slab parity.
   const TrainerDesc &D = *Dp;
   const int nslab = D.B / SLAB;
+  const int per_round = SPLIT == 2 ? nslab : (nslab + 1) / 2;
+  const int idx_ = blk >> 3;
+  const int job = (idx_ / per_round) * 8 + (blk & 7), rest = idx_ % per_round;
+  const int net = job >> 1, sub = job & 1;
+  if (net >= D.ntrain) return;
+  const int half = SPLIT == 2 ? sub : 0;
+  const int slab = SPLIT == 2 ? rest : ((rest << 1) | sub);
   if (slab >= nslab) return;
   const int tile0 = half * (H / 16 / SPLIT) + (threadIdx.x >> 6) * TPH;
   const TrainNet N = D.net[net];
@@ -579,7 +594,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     for (int j = 0; j < N.out_dim; ++j) s += lterm[j * SLAB + tid];
     rowsum[tid] = s;
   }
-  if (half == 0 && net == NET_A && !D.deterministic && tid >= 64 && tid < 64 + D.A) {
+  if (half == 0 && net == D.net_a && !D.deterministic && tid >= 64 && tid < 64 + D.A) {
     const int j = tid - 64;
     float s = 0.f;
 #pragma unroll
@@ -617,7 +632,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
       for (int i = 0; i < 4; ++i) {
         const int rr = 4 * g4 + i;
         float sv = P::round(s[rr]);
-        if (D.has_dropout && net == NET_A) sv = P::round(sv * D.drop_scale);
+        if (D.has_dropout && net == D.net_a) sv = P::round(sv * D.drop_scale);
         outv[i] = h2v[rr] > 0.f ? sv : 0.f;
         dz2s[rr * HP + c2] = P::from_f32(outv[i]);
       }
@@ -651,7 +666,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float s = P::round(acc[jj][i]);
-        if (D.has_dropout && net == NET_A) s = P::round(s * D.drop_scale);
+        if (D.has_dropout && net == D.net_a) s = P::round(s * D.drop_scale);
         outv[i] = h1v[jj][i] > 0.f ? s : 0.f;
       }
       store4T<BF16>(reinterpret_cast<T *>(D.dz1T) + (size_t)net * H * BP +
@@ -748,14 +763,14 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   __shared__ __attribute__((aligned(16))) float tile[UTO * (UMAXI + 4)];
   __shared__ __attribute__((aligned(16))) float tile2[UTO * (UMAXI + 4)];  // layer-1 strip: new targets
   __shared__ float bgrad[UTO];
-  static_assert(UTO * ULD >= 1024, "the misc block reuses the tile as its reduction buffer");
   STAMP(2, 0);
 
   if (blk >= n_items) {
     // ---------------- misc block: log_std, logged losses, step counter ------------
     // all partials are fetched in parallel, then summed in a fixed order from LDS
     float *sred = tile;
-    const int nl = 4 * nslab, na = D.deterministic ? 0 : nslab * D.A;  // nl + na + 4 <= 1024 (host check)
+    const int nt = D.ntrain;
+    const int nl = nt * nslab, na = D.deterministic ? 0 : nslab * D.A;  // nl + na + nt fits the tile (host check)
     for (int e = tid; e < nl + na; e += 256) sred[e] = e < nl ? ldg(D.lossp + e) : ldg(D.lsp + e - nl);
     float ls = 0.f, pm = 0.f, pv = 0.f;
     if (!D.deterministic && tid < D.A) {
@@ -774,7 +789,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       stg(D.params + o, p), stg(D.exp_avg + o, pm), stg(D.exp_avg_sq + o, pv);
       if (D.grads) stg(D.grads + o, g);
     }
-    if (tid >= 64 && tid < 68) {  // one lane per network: fixed-order sum of its slab partials
+    if (tid >= 64 && tid < 64 + nt) {  // one lane per network: fixed-order sum of its slab partials
       const int n = tid - 64;
       float s = 0.f;
       for (int k = 0; k < nslab; ++k) s += sred[n * nslab + k];
@@ -782,9 +797,11 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     }
     __syncthreads();
     if (tid == 64) {
-      const float vl = sred[nl + na + NET_V];
-      const float ql = (sred[nl + na + NET_Q1] + sred[nl + na + NET_Q2]) / 2.f;  // ref:606
-      const float al = sred[nl + na + NET_A];
+      const float vl = sred[nl + na + D.net_v];
+      float ql = 0.f;  // sum(mse(q, targets) for q in qs) / len(qs)  (ref:606)
+      for (int e = 0; e < D.E; ++e) ql += sred[nl + na + e];
+      ql = ql / (float)D.E;
+      const float al = sred[nl + na + D.net_a];
       Cp->last_losses[0] = vl, Cp->last_losses[1] = ql, Cp->last_losses[2] = al;
       Cp->loss_sum[0] += vl, Cp->loss_sum[1] += ql, Cp->loss_sum[2] += al;
       if (A.losses_out) {
@@ -1162,6 +1179,7 @@ __global__ void k_sync_weights(const TrainerDesc *__restrict__ Dp) {
   using P = Prec<BF16>;
   using T = typename P::T;
   const int net = blockIdx.y;
+  if (net >= D.ntrain) return;
   const TrainNet &N = D.net[net];
   const int H = D.H;
   for (int L = 0; L < 3; ++L) {
@@ -1208,7 +1226,7 @@ size_t bwd_smem_bytes(bool bf16, int H) {
 
 hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
                           const DevCtr *c, hipStream_t st) {
-  const int grid = 8 * (D.B / SLAB);
+  const int grid = 8 * ((D.nfwd + 1 + 7) / 8) * (D.B / SLAB);  // nfwd evaluations + the spare job
   const size_t sm = fwd_smem_bytes(bf16, D.H, D.k1max);
 #define CALL(BF, HH) hipLaunchKernelGGL((k_forward<BF, HH>), dim3(grid), dim3(256), sm, st, dD, a, c)
   DISPATCH_H(bf16, D.H, CALL);
@@ -1217,7 +1235,7 @@ hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD
 }
 hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
                            DevCtr *c, hipStream_t st) {
-  const int grid = 8 * (D.H >= 128 ? D.B / SLAB : (D.B / SLAB + 1) / 2);
+  const int grid = 8 * ((2 * D.ntrain + 7) / 8) * (D.H >= 128 ? D.B / SLAB : (D.B / SLAB + 1) / 2);
   const size_t sm = bwd_smem_bytes(bf16, D.H);
 #define CALL(BF, HH) hipLaunchKernelGGL((k_backward<BF, HH>), dim3(grid), dim3(256), sm, st, dD, a, c)
   DISPATCH_H(bf16, D.H, CALL);
@@ -1245,9 +1263,9 @@ hipError_t launch_infer(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, 
 }
 hipError_t launch_sync_weights(bool bf16, const TrainerDesc *dD, hipStream_t st) {
   if (bf16)
-    hipLaunchKernelGGL(k_sync_weights<true>, dim3(32, N_TRAIN), dim3(256), 0, st, dD);
+    hipLaunchKernelGGL(k_sync_weights<true>, dim3(32, MAX_TRAIN), dim3(256), 0, st, dD);
   else
-    hipLaunchKernelGGL(k_sync_weights<false>, dim3(32, N_TRAIN), dim3(256), 0, st, dD);
+    hipLaunchKernelGGL(k_sync_weights<false>, dim3(32, MAX_TRAIN), dim3(256), 0, st, dD);
   return hipGetLastError();
 }
 

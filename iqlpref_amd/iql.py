@@ -69,6 +69,9 @@ class TrainConfig:
     mr_alpha: float = 0.95
     mr_burn_in: int = 0
     reward_model_root: Optional[str] = None
+    # not in the reference: number of critics (2 = the reference's TwinQ; 3..8 = E-way critic
+    # ensemble of BASELINE config 5, see EnsembleQ)
+    n_critics: int = 2
     seed: int = 0
     device: str = "cuda"
 
@@ -375,6 +378,40 @@ class TwinQ(nn.Module):
     def forward(self, state: torch.Tensor, action: torch.Tensor) -> torch.Tensor:
         return torch.min(*self.both(state, action))
 
+    def critics(self) -> List[MLP]:
+        return [self.q1, self.q2]
+
+
+class EnsembleQ(TwinQ):
+    """E-way generalisation of TwinQ (BASELINE config 5 "vectorised critic
+    ensemble"): the same critic MLP E times as submodules q1..qE.  ``both`` returns all E
+    outputs, ``forward`` their minimum; the trainer's q_loss is sum(mse)/E as ref:606 reads
+    for ``len(qs)`` critics.  E = 2 is exactly TwinQ (same state_dict keys)."""
+
+    def __init__(self, state_dim: int, action_dim: int, hidden_dim: int = 256, n_hidden: int = 2,
+                 n_critics: int = 2):
+        if not 2 <= n_critics <= _lib.MAX_CRITICS:
+            raise ValueError(f"n_critics must be in [2, {_lib.MAX_CRITICS}]")
+        super().__init__(state_dim, action_dim, hidden_dim, n_hidden)
+        dims = [state_dim + action_dim, *([hidden_dim] * n_hidden), 1]
+        for e in range(2, n_critics):
+            setattr(self, f"q{e + 1}", MLP(dims, squeeze_output=True))
+        self.n_critics = n_critics
+
+    def critics(self) -> List[MLP]:
+        return [getattr(self, f"q{e + 1}") for e in range(self.n_critics)]
+
+    def both(self, state: torch.Tensor, action: torch.Tensor) -> Tuple[torch.Tensor, ...]:
+        sa = torch.cat([state, action], 1)
+        return tuple(q(sa) for q in self.critics())
+
+    def forward(self, state: torch.Tensor, action: torch.Tensor) -> torch.Tensor:
+        qs = self.both(state, action)
+        out = qs[0]
+        for q in qs[1:]:
+            out = torch.min(out, q)
+        return out
+
 
 class ValueFunction(nn.Module):
     def __init__(self, state_dim: int, hidden_dim: int = 256, n_hidden: int = 2):
@@ -445,13 +482,14 @@ class ImplicitQLearning:
                 not isinstance(actor, (GaussianPolicy, DeterministicPolicy)):
             raise TypeError("networks must be iqlpref_amd TwinQ / ValueFunction / *Policy modules")
         self._deterministic = isinstance(actor, DeterministicPolicy)
-        self._nets = [("q1", _three_linears(q_network.q1, "TwinQ.q1")),
-                      ("q2", _three_linears(q_network.q2, "TwinQ.q2")),
-                      ("v", _three_linears(v_network.v, "ValueFunction")),
-                      ("actor", _three_linears(actor.net, "actor"))]
-        self._state_dim = self._nets[2][1][0].in_features
-        self._action_dim = self._nets[3][1][2].out_features
-        self._hidden = self._nets[2][1][0].out_features
+        crit = q_network.critics()
+        self._n_critics = E = len(crit)
+        self._nets = [(f"q{e + 1}", _three_linears(c, f"TwinQ.q{e + 1}")) for e, c in enumerate(crit)]
+        self._nets += [("v", _three_linears(v_network.v, "ValueFunction")),
+                       ("actor", _three_linears(actor.net, "actor"))]
+        self._state_dim = self._nets[E][1][0].in_features
+        self._action_dim = self._nets[E + 1][1][2].out_features
+        self._hidden = self._nets[E][1][0].out_features
         for _, lin in self._nets:
             if lin[0].out_features != self._hidden or lin[1].in_features != self._hidden or \
                     lin[1].out_features != self._hidden or lin[2].in_features != self._hidden:
@@ -491,6 +529,7 @@ class ImplicitQLearning:
         c.adam_beta1, c.adam_beta2, c.adam_eps = b1, b2, float(g(self.q_optimizer, "eps"))
         c.cosine_t_max = int(self.actor_lr_schedule.T_max)
         c.seed = self._seed
+        c.n_critics = self._n_critics
         return c
 
     def _tensor_list(self) -> List[nn.Parameter]:
@@ -532,11 +571,11 @@ class ImplicitQLearning:
     def _bind_target(self):
         """q_target parameters become views of the target arena (ref:565)."""
         tl = []
-        for mlp in (self.q_target.q1, self.q_target.q2):
+        for mlp in self.q_target.critics():
             for l in mlp.linears():
                 tl += [l.weight, l.bias]
         with torch.no_grad():
-            for p, o in zip(tl, self._offsets[:12]):
+            for p, o in zip(tl, self._offsets[:6 * self._n_critics]):
                 view = self._target[o:o + p.numel()].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
@@ -690,7 +729,7 @@ class ImplicitQLearning:
         self._ensure_handle(self._handle_batch or 32)
         s = states.detach().to(torch.float32).contiguous()
         a = None if actions is None else actions.detach().to(torch.float32).contiguous()
-        width = {0: 2, 1: 1, 2: self._action_dim, 3: 2}[idx]
+        width = {0: self._n_critics, 1: 1, 2: self._action_dim, 3: self._n_critics}[idx]
         out = torch.empty((s.shape[0], width), dtype=torch.float32, device=self._dev)
         with torch.cuda.device(self._dev):
             check(self._lib.iqlhip_forward(self._handle, idx, ptr(s), ptr(a), s.shape[0], ptr(out),

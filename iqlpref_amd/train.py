@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import distributed as D
-from .iql import (DeterministicPolicy, GaussianPolicy, ImplicitQLearning, ReplayBuffer, TrainConfig, TwinQ,
+from .iql import (DeterministicPolicy, EnsembleQ, GaussianPolicy, ImplicitQLearning, ReplayBuffer, TrainConfig, TwinQ,
                   ValueFunction, compute_mean_std, normalize_states, set_seed)
 from .relabel import (load_mlp_reward_model, load_pt_reward_model, modify_reward, qlearning_dataset_bnn,
                       qlearning_dataset_mr, qlearning_dataset_mr_ensemble, qlearning_dataset_pt)
@@ -150,7 +150,10 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
 
     seed = D.rank_seed(config.seed)  # one independent seed per rank / GPU
     set_seed(seed, None)
-    q_network = TwinQ(state_dim, action_dim).to(config.device)
+    if config.n_critics == 2:
+        q_network = TwinQ(state_dim, action_dim).to(config.device)
+    else:
+        q_network = EnsembleQ(state_dim, action_dim, n_critics=config.n_critics).to(config.device)
     v_network = ValueFunction(state_dim).to(config.device)
     pol = DeterministicPolicy if config.iql_deterministic else GaussianPolicy
     actor = pol(state_dim, action_dim, max_action, dropout=config.actor_dropout).to(config.device)

@@ -10,7 +10,8 @@ DEV = "cuda:0"
 def make_nets(hyper, nets, device=DEV):
     qf_p, vf_p, actor_p = nets
     S, A, H = hyper["s_dim"], hyper["a_dim"], hyper["hidden"]
-    q = ia.TwinQ(S, A, hidden_dim=H)
+    E = hyper.get("n_critics", 2)
+    q = ia.TwinQ(S, A, hidden_dim=H) if E == 2 else ia.EnsembleQ(S, A, hidden_dim=H, n_critics=E)
     v = ia.ValueFunction(S, hidden_dim=H)
     cls = ia.DeterministicPolicy if hyper["deterministic"] else ia.GaussianPolicy
     actor = cls(S, A, 1.0, hidden_dim=H, dropout=hyper["dropout"])

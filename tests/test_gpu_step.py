@@ -285,10 +285,15 @@ def test_errors(gh):
         ia.ReplayBuffer(3, 2, 10, "cpu")  # no CPU path
 
 
-@pytest.mark.parametrize("S,A,H,B,det,drop", [(29, 8, 256, 1024, False, None), (45, 24, 256, 256, False, 0.1),
-                                              (17, 6, 128, 48, True, None), (11, 3, 64, 16, False, None)])
+@pytest.mark.parametrize("S,A,H,B,det,drop,E", [
+    (29, 8, 256, 1024, False, None, 2), (45, 24, 256, 256, False, 0.1, 2),
+    (17, 6, 128, 48, True, None, 2), (11, 3, 64, 16, False, None, 2),
+    # BASELINE config 5: E-way critic ensemble (no reference implementation: the oracle's E-way
+    # generalisation of ref:595-613 is the checker, pinned to the reference at E = 2 only)
+    (29, 8, 256, 1024, False, None, 4), (29, 8, 256, 256, False, None, 3), (17, 6, 128, 48, True, None, 8),
+    (11, 3, 64, 32, False, 0.1, 5)])
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_shapes_beyond_the_goldens_vs_oracle(gh, S, A, H, B, det, drop, mode):
+def test_shapes_beyond_the_goldens_vs_oracle(gh, S, A, H, B, det, drop, E, mode):
     """BASELINE configs 3/5 shapes and odd sizes: HIP vs the (reference-pinned) oracle."""
     import iqlpref_amd as ia
     rng = np.random.default_rng(B)
@@ -299,13 +304,16 @@ def test_shapes_beyond_the_goldens_vs_oracle(gh, S, A, H, B, det, drop, mode):
             "next_observations": rng.standard_normal((N, S)).astype(np.float32),
             "terminals": (rng.uniform(size=N) < 0.05).astype(np.float32)}
     torch.manual_seed(B)
-    q, v = ia.TwinQ(S, A, hidden_dim=H), ia.ValueFunction(S, hidden_dim=H)
+    q = ia.TwinQ(S, A, hidden_dim=H) if E == 2 else ia.EnsembleQ(S, A, hidden_dim=H, n_critics=E)
+    v = ia.ValueFunction(S, hidden_dim=H)
     actor = (ia.DeterministicPolicy if det else ia.GaussianPolicy)(S, A, 1.0, hidden_dim=H, dropout=drop)
     sd = lambda m: {k: t.detach().numpy().copy() for k, t in m.state_dict().items()}
     hyper = dict(s_dim=S, a_dim=A, hidden=H, deterministic=det, dropout=drop, iql_tau=0.8, beta=3.0,
-                 max_steps=1000, discount=0.99, tau=0.005, n_rows=N)
+                 max_steps=1000, discount=0.99, tau=0.005, n_rows=N, n_critics=E)
     nets = (sd(q), sd(v), sd(actor))
     tr = gh.make_trainer(hyper, nets, mode, seed=7)
+    assert len(tr.qf.critics()) == E and tr.forward("q", torch.zeros(2, S, device=gh.DEV),
+                                                     torch.zeros(2, A, device=gh.DEV)).shape == (2, E)
     buf = gh.make_buffer(hyper, data)
     K = 3
     got = tr.train_steps(buf, K, B).cpu().numpy()

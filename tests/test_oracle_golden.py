@@ -112,3 +112,42 @@ def test_asymmetric_l2_and_soft_update():
     tgt = {"w": d["soft/tgt_w"].copy()}
     orc.soft_update(tgt, {"w": d["soft/src_w"]}, 0.005)
     np.testing.assert_allclose(tgt["w"], d["soft/out_w"], rtol=1e-6, atol=1e-8)
+
+
+def test_ensemble_oracle_matches_twinq_and_its_own_gradient():
+    """E-way critic generalisation (BASELINE config 5; no reference implementation): at E = 2 the
+    helpers are TwinQ's, and for E = 3 the analytic q-gradient equals a finite difference of
+    q_loss = sum_e mse(q_e, t) / E (ref:606 with len(qs) = E)."""
+    rng = np.random.default_rng(3)
+    S, A, H, B, E = 5, 2, 8, 16, 3
+    qf = {}
+    for e in range(E):
+        for li, (i, o) in enumerate(((S + A, H), (H, H), (H, 1))):
+            qf[f"q{e + 1}.net.{2 * li}.weight"] = rng.standard_normal((o, i)).astype(np.float32) * 0.3
+            qf[f"q{e + 1}.net.{2 * li}.bias"] = rng.standard_normal(o).astype(np.float32) * 0.1
+    assert orc.n_critics(qf) == E
+    s, a = rng.standard_normal((B, S)).astype(np.float32), rng.standard_normal((B, A)).astype(np.float32)
+    t = rng.standard_normal(B).astype(np.float32)
+    two = {k: v for k, v in qf.items() if k.startswith(("q1.", "q2."))}
+    q1, q2, _, _ = orc.twinq_both(two, s, a, "fp32")
+    qs, cs = orc.critics_all(qf, s, a, "fp32")
+    np.testing.assert_array_equal(q1, qs[0])
+    np.testing.assert_array_equal(q2, qs[1])
+    np.testing.assert_array_equal(orc.twinq_forward(qf, s, a, "fp32"), np.minimum(np.minimum(qs[0], qs[1]), qs[2]))
+
+    def loss(p):
+        q, _ = orc.critics_all(p, s, a, "fp32")
+        return sum(np.mean((x.astype(np.float64) - t) ** 2) for x in q) / E
+
+    grads = {}
+    for q, c in zip(qs, cs):
+        g_q = ((np.float32(2) / np.float32(B)) * (q - t)) * (np.float32(1) / np.float32(E))
+        grads.update(orc.mlp_backward(g_q[:, None].astype(np.float32), qf, c, "fp32"))
+    for key, ix in (("q3.net.0.weight", (2, 3)), ("q1.net.2.weight", (4, 1)), ("q2.net.4.bias", (0,))):
+        eps = 1e-3
+        hi = {k: v.copy() for k, v in qf.items()}
+        lo = {k: v.copy() for k, v in qf.items()}
+        hi[key][ix] += eps
+        lo[key][ix] -= eps
+        fd = (loss(hi) - loss(lo)) / (2 * eps)
+        np.testing.assert_allclose(grads[key][ix], fd, rtol=2e-3, atol=1e-6)
