@@ -42,9 +42,9 @@ def synth_dataset(seed, n=N_ROWS):
     }
 
 
-def build_trainer(ia, torch, device, seed, precision):
+def build_trainer(ia, torch, device, seed, precision, n_critics=2):
     torch.manual_seed(seed)
-    q = ia.TwinQ(S_DIM, A_DIM).to(device)
+    q = (ia.TwinQ(S_DIM, A_DIM) if n_critics == 2 else ia.EnsembleQ(S_DIM, A_DIM, n_critics=n_critics)).to(device)
     v = ia.ValueFunction(S_DIM).to(device)
     actor = ia.GaussianPolicy(S_DIM, A_DIM, 1.0).to(device)
     vo = torch.optim.Adam(v.parameters(), lr=3e-4)
@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--unroll", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ensemble-q", type=int, default=4,
+                    help="extra leg (N=1 only): BASELINE configs[4], an E-critic ensemble at batch 1024 "
+                         "(same antmaze shapes); 0 disables.  Reported beside `value`, never as it")
     ap.add_argument("--agents-per-gpu", type=int, default=4,
                     help="extra leg (N=1 only): aggregate steps/s of this many independent seeds sharing "
                          "the GPU on separate streams -- the reference launcher's AGENTS_PER_GPU "
@@ -242,6 +245,19 @@ def main():
             out["agents_per_gpu"] = {"agents": A_, "value": A_ * n_multi / dt_m, "unit": "steps/s",
                                      "steps_per_agent": n_multi,
                                      "note": "aggregate of independent seeds sharing one GPU; not `value`"}
+        if world == 1 and args.ensemble_q >= 2:
+            E_ = args.ensemble_q
+            tre = build_trainer(ia, torch, device, seed + 50, args.precision, n_critics=E_)
+            tre.train_steps(buf, 1_000, 1024, return_losses=False, graph_unroll=args.unroll)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_e = 5_000
+            tre.train_steps(buf, n_e, 1024, return_losses=False, graph_unroll=args.unroll)
+            torch.cuda.synchronize()
+            dt_e = time.perf_counter() - t1
+            out["ensemble_q"] = {"n_critics": E_, "batch": 1024, "value": n_e / dt_e, "unit": "steps/s",
+                                 "transitions_per_s": 1024 * n_e / dt_e,
+                                 "note": "BASELINE configs[4] (E-way critic ensemble, batch 1024); not `value`"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data)
         print(json.dumps(out), flush=True)
