@@ -152,7 +152,8 @@ __device__ __forceinline__ void mlp_slab(const FwdNet &N, const TrainerDesc &D, 
   using K = KCfg<BF16, H>;
   using P = Prec<BF16>;
   using T = typename P::T;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-uniform branches stay scalar
   const int r = lane & 15, q = lane >> 4;
   constexpr int HP = K::HP, TPW = K::TPW;
   const int K1P = D.k1max + P::EPV;
@@ -356,15 +357,21 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
       ix = ix < 0 ? 0 : (ix >= A.n_rows ? A.n_rows - 1 : ix);
       src = A.rows + (size_t)ix * A.row_stride;
     }
+    // unconditional loads from clamped columns (a lane-dependent `c < in_dim ? load : 0` becomes
+    // one branch per load, each followed by s_waitcnt vmcnt(0): eight serial memory latencies);
+    // the padding is zeroed when the values are used
 #pragma unroll
     for (int j = 0; j < NXV; ++j) {
       const int c = l16 + 16 * j;
-      xv[j] = c < N.in_dim ? ldg(src + N.in_off + c) : 0.f;
+      xv[j] = ldg(src + N.in_off + (c < N.in_dim ? c : N.in_dim - 1));
     }
     if (N.stage) {
-      if (l16 < 2) rdv = ldg(src + D.S + D.A + l16);
+      rdv = ldg(src + D.S + D.A + (l16 & 1));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) av[j] = l16 + 16 * j < D.A ? ldg(src + D.S + l16 + 16 * j) : 0.f;
+      for (int j = 0; j < 2; ++j) {
+        const int c = l16 + 16 * j;
+        av[j] = ldg(src + D.S + (c < D.A ? c : D.A - 1));
+      }
     }
   };
   auto fill = [&](T *xs, int K1P) {
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
     for (int j = 0; j < NXV; ++j) {
       const int c = l16 + 16 * j;
       if (c < N.k1pad) {
-        const T tv = P::from_f32(xv[j]);
+        const T tv = P::from_f32(c < N.in_dim ? xv[j] : 0.f);
         xs[rr * K1P + c] = tv;
         if (N.stage && c < N.in_dim) stg(reinterpret_cast<T *>(D.xT) + fidx<P>(c, row, D.BP / P::KM), tv);
       }
@@ -522,9 +529,10 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   const int half = SPLIT == 2 ? sub : 0;
   const int slab = SPLIT == 2 ? rest : ((rest << 1) | sub);
   if (slab >= nslab) return;
-  const int tile0 = half * (H / 16 / SPLIT) + (threadIdx.x >> 6) * TPH;
+  const int tile0 = half * (H / 16 / SPLIT) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * TPH;
   const TrainNet N = D.net[net];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-uniform branches stay scalar
   const int r = lane & 15, q = lane >> 4;
   constexpr int HP = K::HP, TPW = K::TPW;
   const int B = D.B, BP = D.BP, nkb = D.BP / P::KM;
@@ -752,7 +760,8 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   using T = typename P::T;
   const TrainerDesc &D = *Dp;
   const DevArgs &A = *Ap;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-uniform branches stay scalar
   const int r = lane & 15, q = lane >> 4;
   const int H = D.H, B = D.B, BP = D.BP;
   const int nslab = B / SLAB;
@@ -862,19 +871,18 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 #pragma unroll
     for (int k = 0; k < UNF4; ++k) {
       const int e4 = tid + 256 * k;
-      pf[k] = mf[k] = vf[k] = tf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e4 < n4) {
-        pf[k] = __builtin_bit_cast(float4, ldg16(D.params + fbase + 4 * e4));
-        mf[k] = __builtin_bit_cast(float4, ldg16(D.exp_avg + fbase + 4 * e4));
-        vf[k] = __builtin_bit_cast(float4, ldg16(D.exp_avg_sq + fbase + 4 * e4));
-        if (has_target) tf[k] = __builtin_bit_cast(float4, ldg16(D.target + tbase + 4 * e4));
-      }
+      const int ec = e4 < n4 ? e4 : n4 - 1;  // branch-free: lanes past the end re-read the last element
+      pf[k] = __builtin_bit_cast(float4, ldg16(D.params + fbase + 4 * ec));
+      mf[k] = __builtin_bit_cast(float4, ldg16(D.exp_avg + fbase + 4 * ec));
+      vf[k] = __builtin_bit_cast(float4, ldg16(D.exp_avg_sq + fbase + 4 * ec));
+      tf[k] = __builtin_bit_cast(float4, ldg16((has_target ? D.target + tbase : D.params + fbase) + 4 * ec));
     }
-    float pb = 0.f, mb = 0.f, vb = 0.f, tb = 0.f;
-    if (tid < UTO && o0 + tid < Odim) {
-      const int64_t eb = it.off_b + o0 + tid;
+    float pb, mb, vb, tb;  // branch-free (see the tiles below)
+    {
+      const int ob_ = o0 + (tid & (UTO - 1));  // < Odim = H always
+      const int64_t eb = it.off_b + ob_;
       pb = ldg(D.params + eb), mb = ldg(D.exp_avg + eb), vb = ldg(D.exp_avg_sq + eb);
-      if (has_target) tb = ldg(D.target + it.toff_b + o0 + tid);
+      tb = ldg((has_target ? D.target + it.toff_b : D.params + it.off_b) + ob_);
     }
     STAMP(2, 1);
     // dW1^T strip: wave w = out-feature tile w against every in-feature tile (dZ1^T fragments
@@ -882,23 +890,21 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     const T *Xsrc = reinterpret_cast<const T *>(it.Xsrc);
     const T *Zsrc = reinterpret_cast<const T *>(it.Zsrc);
     const int nit = Ipad >> 4;
-    const bool zon = o0 + 16 * wave < Opad;
-    f32x4 acc[UNIT];
+    f32x4 acc[UNIT];  // (Opad = H is a multiple of 64: every wave's out-feature tile exists)
 #pragma unroll
     for (int t = 0; t < UNIT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
-#pragma unroll 1
-    for (int k0 = 0; k0 < nk; k0 += UKC) {
+    auto chunk = [&](const int k0) {
       uint4 zf[UKC], xf[2][UKC];
 #pragma unroll
       for (int ks = 0; ks < UKC; ++ks)
-        if (k0 + ks < nk && zon) {
+        if (k0 + ks < nk) {
           zf[ks] = ldg16(Zsrc + frag_off<P>((o0 >> 4) + wave, k0 + ks, nk, lane));
           xf[0][ks] = ldg16(Xsrc + frag_off<P>(0, k0 + ks, nk, lane));
         }
 #pragma unroll
       for (int t = 0; t < UNIT; ++t) {
-        if (t < nit && zon) {
+        if (t < nit) {
           if (t + 1 < UNIT && t + 1 < nit) {
 #pragma unroll
             for (int ks = 0; ks < UKC; ++ks)
@@ -923,7 +929,10 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
           }
         }
       }
-    }
+    };
+    chunk(0);  // straight-line first chunk: no loop pre-header to drain the state loads in
+#pragma unroll 1
+    for (int k0 = UKC; k0 < nk; k0 += UKC) chunk(k0);
     // C/D layout: lane (r, q) of acc[t] holds dW[o0 + 16 wave + r][16 t + 4 q + k]
 #pragma unroll
     for (int t = 0; t < UNIT; ++t)
@@ -1004,30 +1013,33 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 #pragma unroll
   for (int ps = 0; ps < UNP; ++ps) {
     const int o = o0 + tr + URPP * ps, i = i0 + tc4;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) pw[ps][k] = mw[ps][k] = vw[ps][k] = tw[ps][k] = 0.f;
-    if (o < Odim && i < Idim) {
-      const int64_t e = it.off_w + (int64_t)o * Idim + i;
-      const int64_t te = it.toff_w + (int64_t)o * Idim + i;
-      // Idim = H here: rows of the fp32 masters are 16-byte aligned
+    // Branch-free: every lane loads (rows beyond Odim -- layer 3 has 1 or A rows -- re-read the
+    // last row; their results are never stored).  A guarded load becomes a branch, and the
+    // branch a `s_waitcnt vmcnt(0)`: the loads of one tile would queue behind each other.
+    // Idim = H here: i < Idim always, and rows of the fp32 masters are 16-byte aligned.
+    {
+      const int oc = o < Odim ? o : Odim - 1;
+      const int64_t e = it.off_w + (int64_t)oc * Idim + i;
+      const int64_t te = (has_target ? it.toff_w : it.off_w) + (int64_t)oc * Idim + i;
       const float4 a4 = __builtin_bit_cast(float4, ldg16(D.params + e));
       const float4 b4 = __builtin_bit_cast(float4, ldg16(D.exp_avg + e));
       const float4 c4 = __builtin_bit_cast(float4, ldg16(D.exp_avg_sq + e));
+      // no target network: a dummy read of the parameters keeps the load unconditional
+      const float4 d4 = __builtin_bit_cast(float4, ldg16((has_target ? D.target : D.params) + te));
       pw[ps][0] = a4.x, pw[ps][1] = a4.y, pw[ps][2] = a4.z, pw[ps][3] = a4.w;
       mw[ps][0] = b4.x, mw[ps][1] = b4.y, mw[ps][2] = b4.z, mw[ps][3] = b4.w;
       vw[ps][0] = c4.x, vw[ps][1] = c4.y, vw[ps][2] = c4.z, vw[ps][3] = c4.w;
-      if (has_target) {
-        const float4 d4 = __builtin_bit_cast(float4, ldg16(D.target + te));
-        tw[ps][0] = d4.x, tw[ps][1] = d4.y, tw[ps][2] = d4.z, tw[ps][3] = d4.w;
-      }
+      tw[ps][0] = d4.x, tw[ps][1] = d4.y, tw[ps][2] = d4.z, tw[ps][3] = d4.w;
     }
   }
-  float pb = 0.f, mb = 0.f, vb = 0.f, tb = 0.f;
+  // biases: every thread loads (clamped index, dummy target), threads < 64 of the i0 = 0 tile use them
+  float pb, mb, vb, tb;
   const bool do_bias = i0 == 0;
-  if (do_bias && tid < UTO && o0 + tid < Odim) {
-    const int64_t eb = it.off_b + o0 + tid;
+  {
+    const int ob_ = o0 + (tid & (UTO - 1)) < Odim ? o0 + (tid & (UTO - 1)) : Odim - 1;
+    const int64_t eb = it.off_b + ob_;
     pb = ldg(D.params + eb), mb = ldg(D.exp_avg + eb), vb = ldg(D.exp_avg_sq + eb);
-    if (has_target) tb = ldg(D.target + it.toff_b + o0 + tid);
+    tb = ldg((has_target ? D.target + it.toff_b : D.params + it.off_b) + ob_);
   }
   STAMP(2, 1);
 
@@ -1040,44 +1052,49 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   float bsum[2] = {0.f, 0.f};
   const bool wave_bias = do_bias && wi == 0;
-  const bool xon = ib < Ipad;
-  const bool zon[2] = {ob < Opad, ob + 16 < Opad};
-#pragma unroll 1
-  for (int k0 = 0; k0 < nk; k0 += UKC) {
+  // Branch-free operand stream: in-features always exist here (Idim = H), out-feature tiles
+  // beyond Opad (layer 3: one tile) re-read the last tile -- their products land in tile rows
+  // that are never stored -- and k-steps beyond nk re-read the last one and are skipped by the
+  // (scalar) guard around the MFMA only.
+  const int ntile_o = Opad >> 4;
+  int ot[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) ot[b] = (ob >> 4) + b < ntile_o ? (ob >> 4) + b : ntile_o - 1;
+  // (the first chunk is straight-line code: a loop would make the compiler drain every pending
+  // load -- the optimiser state -- in its pre-header before the operand loads are issued)
+  auto chunk = [&](const int k0) {
     uint4 xf[UKC], zf[UKC][2];
 #pragma unroll
     for (int ks = 0; ks < UKC; ++ks) {
-      if (k0 + ks < nk) {
-        if (xon) xf[ks] = ldg16(Xsrc + frag_off<P>(ib >> 4, k0 + ks, nk, lane));
+      const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
+      xf[ks] = ldg16(Xsrc + frag_off<P>(ib >> 4, kk, nk, lane));
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-          if (zon[b] && (xon || wave_bias))
-            zf[ks][b] = ldg16(Zsrc + frag_off<P>((ob >> 4) + b, k0 + ks, nk, lane));
-      }
+      for (int b = 0; b < 2; ++b) zf[ks][b] = ldg16(Zsrc + frag_off<P>(ot[b], kk, nk, lane));
     }
 #pragma unroll
     for (int ks = 0; ks < UKC; ++ks) {
       if (k0 + ks < nk) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          if (zon[b]) {
-            if (wave_bias) {  // bias gradient = row sums of dZ^T (this lane: its out-feature, 1/4 of K)
-              if constexpr (BF16) {
-                const uint32_t w[4] = {zf[ks][b].x, zf[ks][b].y, zf[ks][b].z, zf[ks][b].w};
+          if (wave_bias) {  // bias gradient = row sums of dZ^T (this lane: its out-feature, 1/4 of K)
+            if constexpr (BF16) {
+              const uint32_t w[4] = {zf[ks][b].x, zf[ks][b].y, zf[ks][b].z, zf[ks][b].w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                  bsum[b] += bf2f((uint16_t)(w[i] & 0xffff)) + bf2f((uint16_t)(w[i] >> 16));
-              } else {
-                const float4 f = __builtin_bit_cast(float4, zf[ks][b]);
-                bsum[b] += (f.x + f.y) + (f.z + f.w);
-              }
+              for (int i = 0; i < 4; ++i)
+                bsum[b] += bf2f((uint16_t)(w[i] & 0xffff)) + bf2f((uint16_t)(w[i] >> 16));
+            } else {
+              const float4 f = __builtin_bit_cast(float4, zf[ks][b]);
+              bsum[b] += (f.x + f.y) + (f.z + f.w);
             }
-            if (xon) P::mma(xf[ks], zf[ks][b], acc[b]);
           }
+          P::mma(xf[ks], zf[ks][b], acc[b]);
         }
       }
     }
-  }
+  };
+  chunk(0);
+#pragma unroll 1
+  for (int k0 = UKC; k0 < nk; k0 += UKC) chunk(k0);
   // C/D layout: lane (r, q) of acc[b] holds dW[ob + 16 b + r][ib + 4 q + k]
 #pragma unroll
   for (int b = 0; b < 2; ++b)
