@@ -169,6 +169,14 @@ __device__ __forceinline__ void mlp_slab(const FwdNet &N, const TrainerDesc &D, 
   // ---- request every weight fragment this wave will need ----
   const int nk1 = N.k1pad / P::KM;
   const int nt3 = N.out_pad / 16;  // 1 or 2
+  // biases first: they are needed at the END of layer 1 / 2, and loads return in order -- behind
+  // the weight stream they would hold layer 1's epilogue until all 160 KB have arrived
+  float bias1[TPW], bias2[TPW];
+#pragma unroll
+  for (int jj = 0; jj < TPW; ++jj) {
+    bias1[jj] = ldg(N.b1 + 16 * (wave * TPW + jj) + r);
+    bias2[jj] = ldg(N.b2 + 16 * (wave * TPW + jj) + r);
+  }
   uint4 w1[K::NK1][TPW], w2[K::NKC][TPW], w3[K::NK3][2];
   const T *W1 = reinterpret_cast<const T *>(N.w1c);
   const T *W2 = reinterpret_cast<const T *>(N.w2c);
@@ -179,15 +187,8 @@ __device__ __forceinline__ void mlp_slab(const FwdNet &N, const TrainerDesc &D, 
   for (int i = 0; i < K::NK3; ++i) {
     const int ks = wave + 4 * i;
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-      if (ks < K::NK2 && jt < nt3)
-        w3[i][jt] = ldg16(W3 + frag_off<P>(jt, ks, K::NK2, lane));
-  }
-  float bias1[TPW], bias2[TPW];
-#pragma unroll
-  for (int jj = 0; jj < TPW; ++jj) {
-    bias1[jj] = ldg(N.b1 + 16 * (wave * TPW + jj) + r);
-    bias2[jj] = ldg(N.b2 + 16 * (wave * TPW + jj) + r);
+    for (int jt = 0; jt < 2; ++jt)  // unconditional (clamped): no branch, no drain of the queue
+      w3[i][jt] = ldg16(W3 + frag_off<P>(jt < nt3 ? jt : 0, ks < K::NK2 ? ks : 0, K::NK2, lane));
   }
 
   STAMP(0, 1);
@@ -428,29 +429,29 @@ __global__ __launch_bounds__(256) void k_infer(const TrainerDesc *__restrict__ D
 // identical instruction sequence, identical bits.
 // ------------------------------------------------------------------------
 struct LossIn {
-  float qtmin, vv, mean, act, ls, nv, qv, rew, done;  // qtmin: min over the E target critics
+  float qt[MAX_CRITICS];  // target critics (entries beyond E repeat the first); reduced in loss_terms,
+                          // so that nothing waits on these loads where they are issued
+  float vv, mean, act, ls, nv, qv, rew, done;
 };
 
 // the loads of loss_terms, separated so that k_backward can issue them before its weight stream
 __device__ __forceinline__ LossIn loss_inputs(const TrainerDesc &D, int net, int b, int j) {
+  // Branch-free: every value any network could need is loaded from a clamped (always valid)
+  // address; loss_terms picks what applies.  Guarded loads would each become a branch followed
+  // by s_waitcnt vmcnt(0), i.e. one memory round trip per value.
   const float *o = D.outs + (size_t)b * D.OUTW;
   LossIn x;
-  x.qtmin = x.vv = x.mean = x.act = x.ls = x.nv = x.qv = x.rew = x.done = 0.f;
-  if (net >= D.net_v) {
-    // TwinQ.forward = min(q1, q2) of the target critics (ref:531-533, 583-584); min over all E
-    x.qtmin = ldg(o + D.out_qt);
-    for (int e = 1; e < D.E; ++e) x.qtmin = fminf(x.qtmin, ldg(o + D.out_qt + e));
-    x.vv = ldg(o + D.out_v);
-    if (net == D.net_a) {
-      x.mean = ldg(o + D.out_mean + j);
-      x.act = ldg(D.actf + (size_t)b * D.A + j);
-      x.ls = D.deterministic ? 0.f : ldg(D.ls_snap + j);
-    }
-  } else {
-    x.nv = ldg(o + D.out_nv);
-    x.qv = ldg(o + net);
-    x.rew = ldg(D.rd + (size_t)b * 2), x.done = ldg(D.rd + (size_t)b * 2 + 1);
-  }
+  // TwinQ.forward = min(q1, q2) of the target critics (ref:531-533, 583-584); min over all E
+#pragma unroll
+  for (int e = 0; e < MAX_CRITICS; ++e) x.qt[e] = ldg(o + D.out_qt + (e < D.E ? e : 0));
+  x.vv = ldg(o + D.out_v);
+  x.nv = ldg(o + D.out_nv);
+  x.qv = ldg(o + (net < D.E ? net : 0));
+  x.rew = ldg(D.rd + (size_t)b * 2), x.done = ldg(D.rd + (size_t)b * 2 + 1);
+  const int jc = j < D.A ? j : D.A - 1;
+  x.mean = ldg(o + D.out_mean + jc);
+  x.act = ldg(D.actf + (size_t)b * D.A + jc);
+  x.ls = ldg((D.deterministic ? D.actf : D.ls_snap) + jc);  // unused when deterministic
   return x;
 }
 
@@ -458,47 +459,51 @@ template <bool BF16>
 __device__ __forceinline__ void loss_terms(const TrainerDesc &D, int net, const LossIn &x, float fB,
                                            float &dz3, float &lterm, float &gstd) {
   using P = Prec<BF16>;
-  const float qtm = x.qtmin, vv = x.vv;
-  gstd = 0.f;
-  if (net == D.net_a) {
-    const float mean = x.mean, act = x.act;
-    float ls = x.ls;
-    const float adv = P::round(qtm - vv);                                      // ref:583-587
-    const float eadv = fminf(P::round(expf(P::round(D.beta * adv))), 100.f);   // ref:622
-    const float gbc = eadv / fB;
-    float gm, bc;
-    if (!D.deterministic) {
-      ls = fminf(fmaxf(ls, -20.f), 2.f);
-      const float sd = expf(ls), var = sd * sd, z = act - mean;
-      // -log_prob (torch.distributions.Normal.log_prob)
-      bc = (z * z) / (2.f * var) + logf(sd) + 0.9189385332046727f;
-      gm = P::round(-gbc * (z / var));
-      gstd = gbc * (-(z * z) / (var * sd) + 1.f / sd);
-    } else {
-      const float z = mean - act;  // ref:629
-      bc = z * z;
-      gm = P::round(gbc * 2.f * z);
-    }
-    lterm = eadv * bc;
-    dz3 = P::round(gm * (1.f - mean * mean));  // tanh backward
-  } else if (net == D.net_v) {
-    const float adv = P::round(qtm - vv);
-    const float w = fabsf(D.iql_tau - (adv < 0.f ? 1.f : 0.f));  // ref:404-405
-    lterm = w * P::round(adv * adv);
-    float g;
-    if constexpr (BF16)
-      g = rbf(rbf(w / fB) * (2.f * adv));
-    else
-      g = (w / fB) * (2.f * adv);
-    dz3 = -g;  // adv = target_q - v
-  } else {
-    const float target = x.rew + (1.f - x.done) * D.discount * x.nv;  // ref:604
-    const float diff = x.qv - target;
-    lterm = diff * diff;
-    // q_loss = sum_e mse(q_e, t) / E (ref:606): the division hands 1/E to each mse term, whose
-    // backward is (2/B) * (q - t) * grad_out; for E = 2 and B a power of two = (q - t) / B
-    dz3 = P::round((D.two_over_B * diff) * D.inv_E);
-  }
+  // Branch-free on purpose: all three variants are evaluated and one is selected.  With
+  // `if (net == actor) {...}` the compiler sinks the loads of mean / action / log_std into the
+  // branch, behind the weight stream -- one more memory round trip before the loss is known.
+  float qtm = x.qt[0];
+#pragma unroll
+  for (int e = 1; e < MAX_CRITICS; ++e) qtm = fminf(qtm, x.qt[e]);
+  const float vv = x.vv;
+  const float adv = P::round(qtm - vv);                                        // ref:583-587
+  // ---- actor (AWR, ref:615-637) ----
+  const float mean = x.mean, act = x.act;
+  const float eadv = fminf(P::round(expf(P::round(D.beta * adv))), 100.f);     // ref:622
+  const float gbc = eadv / fB;
+  const float lsc = fminf(fmaxf(x.ls, -20.f), 2.f);
+  const float sd = expf(lsc), var = sd * sd, zg = act - mean;
+  // -log_prob (torch.distributions.Normal.log_prob)
+  const float bc_g = (zg * zg) / (2.f * var) + logf(sd) + 0.9189385332046727f;
+  const float gm_g = P::round(-gbc * (zg / var));
+  const float gstd_g = gbc * (-(zg * zg) / (var * sd) + 1.f / sd);
+  const float zd = mean - act;  // ref:629
+  const float bc_d = zd * zd;
+  const float gm_d = P::round(gbc * 2.f * zd);
+  const bool det = D.deterministic != 0;
+  const float bc = det ? bc_d : bc_g, gm = det ? gm_d : gm_g;
+  const float lterm_a = eadv * bc;
+  const float dz3_a = P::round(gm * (1.f - mean * mean));  // tanh backward
+  // ---- V (expectile, ref:404-405, 581-593) ----
+  const float w = fabsf(D.iql_tau - (adv < 0.f ? 1.f : 0.f));
+  const float lterm_v = w * P::round(adv * adv);
+  float g;
+  if constexpr (BF16)
+    g = rbf(rbf(w / fB) * (2.f * adv));
+  else
+    g = (w / fB) * (2.f * adv);
+  const float dz3_v = -g;  // adv = target_q - v
+  // ---- critics (TD, ref:595-613) ----
+  const float target = x.rew + (1.f - x.done) * D.discount * x.nv;  // ref:604
+  const float diff = x.qv - target;
+  const float lterm_q = diff * diff;
+  // q_loss = sum_e mse(q_e, t) / E (ref:606): the division hands 1/E to each mse term, whose
+  // backward is (2/B) * (q - t) * grad_out; for E = 2 and B a power of two = (q - t) / B
+  const float dz3_q = P::round((D.two_over_B * diff) * D.inv_E);
+  const bool is_a = net == D.net_a, is_v = net == D.net_v;
+  dz3 = is_a ? dz3_a : (is_v ? dz3_v : dz3_q);
+  lterm = is_a ? lterm_a : (is_v ? lterm_v : lterm_q);
+  gstd = (is_a && !det) ? gstd_g : 0.f;
 }
 
 // ========================================================================
@@ -549,16 +554,31 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
 
   // ---- the loss inputs first: loads return in order, these must not queue behind the
   // weight stream requested next (thread e -> row e / out_dim, output e % out_dim) ----
-  LossIn lin[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int e = tid + 256 * u;
-    if (e < SLAB * N.out_dim) lin[u] = loss_inputs(D, net, slab * SLAB + e / N.out_dim, e % N.out_dim);
-  }
-  // ---- request everything else that does not depend on the loss ----
-  uint4 w2t[K::NKC][TPH];
+  // thread -> (row tid / 16, outputs tid % 16 and tid % 16 + 16): the per-row values are shared
+  // by both outputs, the second output only adds its mean / action / log_std (A <= 32)
+  const int lrow = tid >> 4, lj = tid & 15;
+  LossIn lin = loss_inputs(D, net, slab * SLAB + lrow, lj);
+  // keep these loads AHEAD of the weight stream (the scheduler otherwise moves some of them
+  // behind it, and loads return in order)
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- request everything else that does not depend on the loss, in the order it is
+  // consumed (loads return in order): W3 and h2 for the dZ2 phase, then the W2^T stream for
+  // the GEMM, h1 for its epilogue.  All unconditional (clamped), see loss_inputs. ----
   const T *W2T = reinterpret_cast<const T *>(N.w2ct);
   const T *W3c = reinterpret_cast<const T *>(N.wc[2]);
+  const int c2 = tid < H ? tid : H - 1;  // hidden unit this thread owns in the dZ2 phase
+  float h2v[16], w3v[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j)  // used for j < out_dim only; rows beyond out_pad re-read row 0
+    w3v[j] = P::to_f32(ldg(W3c + fidx<P>(j < N.out_pad ? j : 0, c2, K::NK2)));
+  {
+    const T *h2T = reinterpret_cast<const T *>(D.hT) + (size_t)(net * 2 + 1) * H * BP;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      load4T<BF16>(h2T + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), &h2v[4 * g4]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  uint4 w2t[K::NKC][TPH];
   load_w<P, K::NKC, TPH>(w2t, W2T, K::NK2, 0, K::NKC, tile0, lane);
   float h1v[TPH][4];
 #pragma unroll
@@ -566,32 +586,25 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     load4T<BF16>(reinterpret_cast<const T *>(D.hT) + (size_t)(net * 2 + 0) * H * BP +
                      fidx<P>(16 * (tile0 + jj) + r, slab * SLAB + 4 * q, nkb),
                  h1v[jj]);
-  const int c2 = tid;  // hidden unit this thread owns in the dZ2 phase
-  float h2v[16], w3v[32];
-  if (c2 < H) {
-    const T *h2T = reinterpret_cast<const T *>(D.hT) + (size_t)(net * 2 + 1) * H * BP;
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4)
-      load4T<BF16>(h2T + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), &h2v[4 * g4]);
-#pragma unroll
-    for (int j = 0; j < 32; ++j)
-      w3v[j] = j < N.out_dim
-                   ? P::to_f32(ldg(W3c + fidx<P>(j, c2, K::NK2)))
-                   : 0.f;
-  }
 
   // ---- per-row loss terms and d(loss)/d(out)  (ref:581-637) ----
   STAMP(1, 1);
   // LDS layout [j][16 rows]: the dZ2 phase reads four rows per instruction
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int e = tid + 256 * u;
-    if (e < SLAB * N.out_dim) {
-      const int rr = e / N.out_dim, j = e - rr * N.out_dim;
-      float d3, lt, gs;
-      loss_terms<BF16>(D, net, lin[u], fB, d3, lt, gs);
-      dz3[j * SLAB + rr] = d3, lterm[j * SLAB + rr] = lt, gstd[j * SLAB + rr] = gs;
-    }
+  {
+    float d3, lt, gs;
+    loss_terms<BF16>(D, net, lin, fB, d3, lt, gs);
+    if (lj < N.out_dim) dz3[lj * SLAB + lrow] = d3, lterm[lj * SLAB + lrow] = lt, gstd[lj * SLAB + lrow] = gs;
+  }
+  if (N.out_dim > 16) {
+    // outputs 16 .. A-1 (pen: A = 24): the second output of this thread's row reuses the row
+    // values and fetches its own mean / action / log_std here (one more round trip, actor only)
+    const int j = lj + 16, jc = j < D.A ? j : D.A - 1;
+    lin.mean = ldg(D.outs + (size_t)(slab * SLAB + lrow) * D.OUTW + D.out_mean + jc);
+    lin.act = ldg(D.actf + (size_t)(slab * SLAB + lrow) * D.A + jc);
+    lin.ls = ldg((D.deterministic ? D.actf : D.ls_snap) + jc);
+    float d3, lt, gs;
+    loss_terms<BF16>(D, net, lin, fB, d3, lt, gs);
+    if (j < N.out_dim) dz3[j * SLAB + lrow] = d3, lterm[j * SLAB + lrow] = lt, gstd[j * SLAB + lrow] = gs;
   }
   __syncthreads();
   STAMP(1, 2);
@@ -617,7 +630,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   }
 
   // ---- dZ2 = (dZ3 W3) * relu'(h2)   (VALU: K = out_dim <= 32) ----
-  if (c2 < H) {
+  if (tid < H) {
     T *dst = reinterpret_cast<T *>(D.dz2T) + (size_t)net * H * BP;
     float s[SLAB];
 #pragma unroll
