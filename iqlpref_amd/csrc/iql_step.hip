@@ -907,39 +907,59 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 #pragma unroll
     for (int t = 0; t < UNIT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
+    // All operand fragments of the first three in-feature tiles (S + A <= 48: all of them) are
+    // requested up front, unconditionally (clamped indices): guards only around the MFMAs.
+    constexpr int TB = 3;
     auto chunk = [&](const int k0) {
-      uint4 zf[UKC], xf[2][UKC];
+      uint4 zf[UKC], xf[TB][UKC];
 #pragma unroll
-      for (int ks = 0; ks < UKC; ++ks)
-        if (k0 + ks < nk) {
-          zf[ks] = ldg16(Zsrc + frag_off<P>((o0 >> 4) + wave, k0 + ks, nk, lane));
-          xf[0][ks] = ldg16(Xsrc + frag_off<P>(0, k0 + ks, nk, lane));
+      for (int ks = 0; ks < UKC; ++ks) {
+        const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
+        zf[ks] = ldg16(Zsrc + frag_off<P>((o0 >> 4) + wave, kk, nk, lane));
+      }
+#pragma unroll
+      for (int tb = 0; tb < TB; ++tb) {
+        const int tt = tb < nit ? tb : nit - 1;
+#pragma unroll
+        for (int ks = 0; ks < UKC; ++ks) {
+          const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
+          xf[tb][ks] = ldg16(Xsrc + frag_off<P>(tt, kk, nk, lane));
         }
+      }
 #pragma unroll
-      for (int t = 0; t < UNIT; ++t) {
-        if (t < nit) {
-          if (t + 1 < UNIT && t + 1 < nit) {
+      for (int ks = 0; ks < UKC; ++ks) {
+        if (k0 + ks < nk) {  // bias gradient = row sums of dZ^T
+          if constexpr (BF16) {
+            const uint32_t w[4] = {zf[ks].x, zf[ks].y, zf[ks].z, zf[ks].w};
 #pragma unroll
-            for (int ks = 0; ks < UKC; ++ks)
-              if (k0 + ks < nk) xf[(t + 1) & 1][ks] = ldg16(Xsrc + frag_off<P>(t + 1, k0 + ks, nk, lane));
+            for (int i = 0; i < 4; ++i) bsum += bf2f((uint16_t)(w[i] & 0xffff)) + bf2f((uint16_t)(w[i] >> 16));
+          } else {
+            const float4 f = __builtin_bit_cast(float4, zf[ks]);
+            bsum += (f.x + f.y) + (f.z + f.w);
           }
+        }
+      }
+#pragma unroll
+      for (int tb = 0; tb < TB; ++tb) {
+        if (tb < nit) {
+#pragma unroll
+          for (int ks = 0; ks < UKC; ++ks)
+            if (k0 + ks < nk) P::mma(xf[tb][ks], zf[ks], acc[tb]);
+        }
+      }
+      // wider inputs (S + A > 48): the remaining tiles one at a time
+#pragma unroll
+      for (int t = TB; t < UNIT; ++t) {
+        if (t < nit) {
+          uint4 xg[UKC];
 #pragma unroll
           for (int ks = 0; ks < UKC; ++ks) {
-            if (k0 + ks < nk) {
-              if (t == 0) {  // bias gradient = row sums of dZ^T
-                if constexpr (BF16) {
-                  const uint32_t w[4] = {zf[ks].x, zf[ks].y, zf[ks].z, zf[ks].w};
-#pragma unroll
-                  for (int i = 0; i < 4; ++i)
-                    bsum += bf2f((uint16_t)(w[i] & 0xffff)) + bf2f((uint16_t)(w[i] >> 16));
-                } else {
-                  const float4 f = __builtin_bit_cast(float4, zf[ks]);
-                  bsum += (f.x + f.y) + (f.z + f.w);
-                }
-              }
-              P::mma(xf[t & 1][ks], zf[ks], acc[t]);
-            }
+            const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
+            xg[ks] = ldg16(Xsrc + frag_off<P>(t, kk, nk, lane));
           }
+#pragma unroll
+          for (int ks = 0; ks < UKC; ++ks)
+            if (k0 + ks < nk) P::mma(xg[ks], zf[ks], acc[t]);
         }
       }
     };
