@@ -322,7 +322,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
     };
     for (int o0 = 0; o0 < H; o0 += 64)
       for (int i0 = 0; i0 < H; i0 += 32) put(1, o0, i0);
-    for (int o0 = 0; o0 < H; o0 += 64) put(0, o0, 0);  // layer 1: strips over all in-features
+    for (int o0 = 0; o0 < H; o0 += 32) put(0, o0, 0);  // layer 1: 32-row strips over all in-features
     for (int o0 = 0; o0 < outpad[n]; o0 += 64)
       for (int i0 = 0; i0 < H; i0 += 32) put(2, o0, i0);
   }

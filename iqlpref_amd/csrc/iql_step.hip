@@ -762,7 +762,8 @@ constexpr int URPP = 256 / UTPR; // rows per pass
 constexpr int UNP = UTO / URPP;  // passes
 constexpr int UMAXI = 128;       // S + A <= 128 (host check)
 constexpr int UNIT = UMAXI / 16; // in-feature tiles of a layer-1 strip, at most
-constexpr int UNF4 = 3;          // float4 of the flat range per thread held in registers (S + A <= 48)
+constexpr int USR = 32;          // rows of a layer-1 strip
+constexpr int UNF4 = 2;          // float4 of the strip's flat range per thread in registers (S + A <= 64)
 
 template <bool BF16>
 __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
@@ -873,12 +874,13 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   const int nk = BP / P::KM;
 
   if (L == 0) {
-    // =========== layer 1: a strip of 64 out-features x ALL in-features ===========
+    // =========== layer 1: a strip of 32 out-features x ALL in-features ===========
     // Rows of W1 (S + A floats) are not 16-byte aligned, so the strip's optimiser state is
-    // streamed as ONE flat range o0*Idim .. (o0+64)*Idim: consecutive lanes, consecutive
-    // addresses, every line fully used.
+    // streamed as ONE flat range o0*Idim .. (o0+32)*Idim: consecutive lanes, consecutive
+    // addresses, every line fully used.  (32 rather than 64 rows: the strips are the longest
+    // work-groups of the launch, twice as many halves the tail.)
     const int TLD = Ipad + 4;
-    const int n4 = UTO * Idim / 4;  // Odim = H is a multiple of 64: the strip is always 64 full rows
+    const int n4 = USR * Idim / 4;  // Odim = H is a multiple of 32: the strip is always 32 full rows
     const int64_t fbase = it.off_w + (int64_t)o0 * Idim, tbase = it.toff_w + (int64_t)o0 * Idim;
     float4 pf[UNF4], mf[UNF4], vf[UNF4], tf[UNF4];
 #pragma unroll
@@ -892,87 +894,95 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     }
     float pb, mb, vb, tb;  // branch-free (see the tiles below)
     {
-      const int ob_ = o0 + (tid & (UTO - 1));  // < Odim = H always
+      const int ob_ = o0 + (tid & (USR - 1));  // < Odim = H always
       const int64_t eb = it.off_b + ob_;
       pb = ldg(D.params + eb), mb = ldg(D.exp_avg + eb), vb = ldg(D.exp_avg_sq + eb);
       tb = ldg((has_target ? D.target + it.toff_b : D.params + it.off_b) + ob_);
     }
     STAMP(2, 1);
-    // dW1^T strip: wave w = out-feature tile w against every in-feature tile (dZ1^T fragments
-    // stay in registers across the in-feature tiles)
+    // dW1^T strip: wave w = out-feature tile (w & 1) against the in-feature tiles of parity
+    // (w >> 1): every element is produced by one wave, k-steps in order (no cross-wave sums)
     const T *Xsrc = reinterpret_cast<const T *>(it.Xsrc);
     const T *Zsrc = reinterpret_cast<const T *>(it.Zsrc);
     const int nit = Ipad >> 4;
-    f32x4 acc[UNIT];  // (Opad = H is a multiple of 64: every wave's out-feature tile exists)
+    const int wo = wave & 1, th = wave >> 1;
+    constexpr int NT = UNIT / 2;  // in-feature tiles per wave, at most
+    f32x4 acc[NT];
 #pragma unroll
-    for (int t = 0; t < UNIT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
-    // All operand fragments of the first three in-feature tiles (S + A <= 48: all of them) are
-    // requested up front, unconditionally (clamped indices): guards only around the MFMAs.
-    constexpr int TB = 3;
+    // The operand fragments of this wave's first two in-feature tiles (S + A <= 64: all of
+    // them) are requested up front, unconditionally (clamped indices): guards only around the MFMAs.
+    constexpr int TB = 2;
     auto chunk = [&](const int k0) {
       uint4 zf[UKC], xf[TB][UKC];
 #pragma unroll
       for (int ks = 0; ks < UKC; ++ks) {
         const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
-        zf[ks] = ldg16(Zsrc + frag_off<P>((o0 >> 4) + wave, kk, nk, lane));
+        zf[ks] = ldg16(Zsrc + frag_off<P>((o0 >> 4) + wo, kk, nk, lane));
       }
 #pragma unroll
       for (int tb = 0; tb < TB; ++tb) {
-        const int tt = tb < nit ? tb : nit - 1;
+        const int tt = th + 2 * tb < nit ? th + 2 * tb : nit - 1;
 #pragma unroll
         for (int ks = 0; ks < UKC; ++ks) {
           const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
           xf[tb][ks] = ldg16(Xsrc + frag_off<P>(tt, kk, nk, lane));
         }
       }
+      if (th == 0) {
 #pragma unroll
-      for (int ks = 0; ks < UKC; ++ks) {
-        if (k0 + ks < nk) {  // bias gradient = row sums of dZ^T
-          if constexpr (BF16) {
-            const uint32_t w[4] = {zf[ks].x, zf[ks].y, zf[ks].z, zf[ks].w};
+        for (int ks = 0; ks < UKC; ++ks) {
+          if (k0 + ks < nk) {  // bias gradient = row sums of dZ^T
+            if constexpr (BF16) {
+              const uint32_t w[4] = {zf[ks].x, zf[ks].y, zf[ks].z, zf[ks].w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bsum += bf2f((uint16_t)(w[i] & 0xffff)) + bf2f((uint16_t)(w[i] >> 16));
-          } else {
-            const float4 f = __builtin_bit_cast(float4, zf[ks]);
-            bsum += (f.x + f.y) + (f.z + f.w);
+              for (int i = 0; i < 4; ++i)
+                bsum += bf2f((uint16_t)(w[i] & 0xffff)) + bf2f((uint16_t)(w[i] >> 16));
+            } else {
+              const float4 f = __builtin_bit_cast(float4, zf[ks]);
+              bsum += (f.x + f.y) + (f.z + f.w);
+            }
           }
         }
       }
 #pragma unroll
       for (int tb = 0; tb < TB; ++tb) {
-        if (tb < nit) {
+        if (th + 2 * tb < nit) {
 #pragma unroll
           for (int ks = 0; ks < UKC; ++ks)
             if (k0 + ks < nk) P::mma(xf[tb][ks], zf[ks], acc[tb]);
         }
       }
-      // wider inputs (S + A > 48): the remaining tiles one at a time
+      // wider inputs (S + A > 64): the remaining tiles one at a time
 #pragma unroll
-      for (int t = TB; t < UNIT; ++t) {
-        if (t < nit) {
+      for (int tb = TB; tb < NT; ++tb) {
+        if (th + 2 * tb < nit) {
           uint4 xg[UKC];
 #pragma unroll
           for (int ks = 0; ks < UKC; ++ks) {
             const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
-            xg[ks] = ldg16(Xsrc + frag_off<P>(t, kk, nk, lane));
+            xg[ks] = ldg16(Xsrc + frag_off<P>(th + 2 * tb, kk, nk, lane));
           }
 #pragma unroll
           for (int ks = 0; ks < UKC; ++ks)
-            if (k0 + ks < nk) P::mma(xg[ks], zf[ks], acc[t]);
+            if (k0 + ks < nk) P::mma(xg[ks], zf[ks], acc[tb]);
         }
       }
     };
     chunk(0);  // straight-line first chunk: no loop pre-header to drain the state loads in
 #pragma unroll 1
     for (int k0 = UKC; k0 < nk; k0 += UKC) chunk(k0);
-    // C/D layout: lane (r, q) of acc[t] holds dW[o0 + 16 wave + r][16 t + 4 q + k]
+    // C/D layout: lane (r, q) of acc[tb] holds dW[o0 + 16 wo + r][16 (th + 2 tb) + 4 q + k]
 #pragma unroll
-    for (int t = 0; t < UNIT; ++t)
-      if (t < nit) *reinterpret_cast<f32x4 *>(&tile[(16 * wave + r) * TLD + 16 * t + 4 * q]) = acc[t];
-    bsum += __shfl_xor(bsum, 16);
-    bsum += __shfl_xor(bsum, 32);
-    if (q == 0) bgrad[16 * wave + r] = bsum;
+    for (int tb = 0; tb < NT; ++tb)
+      if (th + 2 * tb < nit)
+        *reinterpret_cast<f32x4 *>(&tile[(16 * wo + r) * TLD + 16 * (th + 2 * tb) + 4 * q]) = acc[tb];
+    if (th == 0) {
+      bsum += __shfl_xor(bsum, 16);
+      bsum += __shfl_xor(bsum, 32);
+      if (q == 0) bgrad[16 * wo + r] = bsum;
+    }
     __syncthreads();
     STAMP(2, 3);
     T *wc = reinterpret_cast<T *>(it.wc);
@@ -1006,13 +1016,13 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       const int e4 = tid + 256 * k;
       if (e4 < n4) flat_update(e4, pf[k], mf[k], vf[k], tf[k]);
     }
-    for (int e4 = tid + 256 * UNF4; e4 < n4; e4 += 256)  // wide inputs (S + A > 48): from memory
+    for (int e4 = tid + 256 * UNF4; e4 < n4; e4 += 256)  // wide inputs (S + A > 64): from memory
       flat_update(e4, __builtin_bit_cast(float4, ldg16(D.params + fbase + 4 * e4)),
                   __builtin_bit_cast(float4, ldg16(D.exp_avg + fbase + 4 * e4)),
                   __builtin_bit_cast(float4, ldg16(D.exp_avg_sq + fbase + 4 * e4)),
                   has_target ? __builtin_bit_cast(float4, ldg16(D.target + tbase + 4 * e4))
                              : make_float4(0.f, 0.f, 0.f, 0.f));
-    if (tid < UTO && o0 + tid < Odim) {
+    if (tid < USR) {
       const int64_t e = it.off_b + o0 + tid;
       const float g = P::round(bgrad[tid]);
       adam_apply(pb, mb, vb, g, coef, neg_step);
@@ -1024,7 +1034,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     // compute copies: 4 consecutive in-features of one row are contiguous in the fragment-major
     // image (columns Idim .. Ipad of the tile hold zero gradients = the copies' zero padding)
     const int cpr = Ipad >> 2;
-    for (int e = tid; e < UTO * cpr; e += 256) {
+    for (int e = tid; e < USR * cpr; e += 256) {
       const int ol = e / cpr, i = (e - ol * cpr) * 4;
       const float4 p4 = *reinterpret_cast<const float4 *>(&tile[ol * TLD + i]);
       float pv4[4] = {p4.x, p4.y, p4.z, p4.w};
