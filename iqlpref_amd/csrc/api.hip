@@ -21,6 +21,7 @@ hipError_t launch_forward(bool, const TrainerDesc &, const TrainerDesc *, const 
                           hipStream_t);
 hipError_t launch_backward(bool, const TrainerDesc &, const TrainerDesc *, const DevArgs *, DevCtr *,
                            hipStream_t);
+int strip_rows();
 hipError_t launch_update(bool, const TrainerDesc *, const DevArgs *, DevCtr *, const UpdItem *, int,
                          hipStream_t);
 hipError_t launch_sync_weights(bool, const TrainerDesc *, hipStream_t);
@@ -322,7 +323,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
     };
     for (int o0 = 0; o0 < H; o0 += 64)
       for (int i0 = 0; i0 < H; i0 += 32) put(1, o0, i0);
-    for (int o0 = 0; o0 < H; o0 += 32) put(0, o0, 0);  // layer 1: 32-row strips over all in-features
+    for (int o0 = 0; o0 < H; o0 += strip_rows()) put(0, o0, 0);  // layer 1: strips over all in-features
     for (int o0 = 0; o0 < outpad[n]; o0 += 64)
       for (int i0 = 0; i0 < H; i0 += 32) put(2, o0, i0);
   }

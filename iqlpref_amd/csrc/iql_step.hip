@@ -762,8 +762,13 @@ constexpr int URPP = 256 / UTPR; // rows per pass
 constexpr int UNP = UTO / URPP;  // passes
 constexpr int UMAXI = 128;       // S + A <= 128 (host check)
 constexpr int UNIT = UMAXI / 16; // in-feature tiles of a layer-1 strip, at most
-constexpr int USR = 32;          // rows of a layer-1 strip
-constexpr int UNF4 = 2;          // float4 of the strip's flat range per thread in registers (S + A <= 64)
+#ifndef IQL_USR
+#define IQL_USR 16
+#endif
+constexpr int USR = IQL_USR;     // rows of a layer-1 strip (16 or 32)
+constexpr int UOT = USR / 16;    // out-feature tiles of a strip
+constexpr int UWPO = 4 / UOT;    // waves sharing one out-feature tile (they split the in-feature tiles)
+constexpr int UNF4 = 2;          // float4 of the strip's flat range per thread in registers
 
 template <bool BF16>
 __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
@@ -905,13 +910,13 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     const T *Xsrc = reinterpret_cast<const T *>(it.Xsrc);
     const T *Zsrc = reinterpret_cast<const T *>(it.Zsrc);
     const int nit = Ipad >> 4;
-    const int wo = wave & 1, th = wave >> 1;
-    constexpr int NT = UNIT / 2;  // in-feature tiles per wave, at most
+    const int wo = wave % UOT, th = wave / UOT;
+    constexpr int NT = UNIT / UWPO;  // in-feature tiles per wave, at most
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
-    // The operand fragments of this wave's first two in-feature tiles (S + A <= 64: all of
+    // The operand fragments of this wave's first two in-feature tiles (16-row strips: all of
     // them) are requested up front, unconditionally (clamped indices): guards only around the MFMAs.
     constexpr int TB = 2;
     auto chunk = [&](const int k0) {
@@ -923,7 +928,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       }
 #pragma unroll
       for (int tb = 0; tb < TB; ++tb) {
-        const int tt = th + 2 * tb < nit ? th + 2 * tb : nit - 1;
+        const int tt = th + UWPO * tb < nit ? th + UWPO * tb : nit - 1;
 #pragma unroll
         for (int ks = 0; ks < UKC; ++ks) {
           const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
@@ -948,7 +953,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       }
 #pragma unroll
       for (int tb = 0; tb < TB; ++tb) {
-        if (th + 2 * tb < nit) {
+        if (th + UWPO * tb < nit) {
 #pragma unroll
           for (int ks = 0; ks < UKC; ++ks)
             if (k0 + ks < nk) P::mma(xf[tb][ks], zf[ks], acc[tb]);
@@ -957,12 +962,12 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       // wider inputs (S + A > 64): the remaining tiles one at a time
 #pragma unroll
       for (int tb = TB; tb < NT; ++tb) {
-        if (th + 2 * tb < nit) {
+        if (th + UWPO * tb < nit) {
           uint4 xg[UKC];
 #pragma unroll
           for (int ks = 0; ks < UKC; ++ks) {
             const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
-            xg[ks] = ldg16(Xsrc + frag_off<P>(th + 2 * tb, kk, nk, lane));
+            xg[ks] = ldg16(Xsrc + frag_off<P>(th + UWPO * tb, kk, nk, lane));
           }
 #pragma unroll
           for (int ks = 0; ks < UKC; ++ks)
@@ -976,8 +981,8 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     // C/D layout: lane (r, q) of acc[tb] holds dW[o0 + 16 wo + r][16 (th + 2 tb) + 4 q + k]
 #pragma unroll
     for (int tb = 0; tb < NT; ++tb)
-      if (th + 2 * tb < nit)
-        *reinterpret_cast<f32x4 *>(&tile[(16 * wo + r) * TLD + 16 * (th + 2 * tb) + 4 * q]) = acc[tb];
+      if (th + UWPO * tb < nit)
+        *reinterpret_cast<f32x4 *>(&tile[(16 * wo + r) * TLD + 16 * (th + UWPO * tb) + 4 * q]) = acc[tb];
     if (th == 0) {
       bsum += __shfl_xor(bsum, 16);
       bsum += __shfl_xor(bsum, 32);
@@ -1302,6 +1307,7 @@ hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *d
 #undef CALL
   return hipGetLastError();
 }
+int strip_rows() { return USR; }
 hipError_t launch_update(bool bf16, const TrainerDesc *dD, const DevArgs *a, DevCtr *c,
                          const UpdItem *items, int n_items, hipStream_t st) {
   if (bf16)
