@@ -1193,6 +1193,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       if (has_target) store4T<BF16>(tc + fidx<P>(o, i, nkw), tv);
     }
   }
+  STAMP(2, 5);
   // ---- bias: thread t < 64 owns out-feature o0 + t ----
   if (do_bias && tid < UTO && o0 + tid < Odim) {
     const int64_t e = it.off_b + o0 + tid;
@@ -1202,6 +1203,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     if (D.grads) stg(D.grads + e, g);
     if (has_target) stg(D.target + it.toff_b + o0 + tid, tb + D.tau * (pb - tb));
   }
+  STAMP(2, 6);
   // ---- 4. transposed compute copy of layer 2 for the backward GEMM: [in][out] ----
   if (L == 1) {
     __syncthreads();

@@ -53,7 +53,8 @@ for k in range(3):
     for slots, blks in sorted(kinds.items(), key=lambda kv: -len(kv[1])):
         ww = w[blks]
         line = f"   kind slots={list(slots)} n={len(blks)}: "
-        for a_, b_ in zip(slots[:-1], slots[1:]):
+        order = sorted(slots, key=lambda sl: np.median(ww[:, sl]))
+        for a_, b_ in zip(order[:-1], order[1:]):
             dt = (ww[:, b_] - ww[:, a_]) * 10
             line += f" {a_}->{b_} med {np.median(dt):6.0f} max {dt.max():6.0f} |"
         tot = (ww[:, slots[-1]] - ww[:, slots[0]]) * 10
