@@ -233,21 +233,12 @@ def main():
             # independent seeds on independent streams; same dataset (a sweep varies the seed only)
             A_ = args.agents_per_gpu
             trs = [tr] + [build_trainer(ia, torch, device, seed + 100 + i, args.precision) for i in range(1, A_)]
-            streams = [torch.cuda.Stream() for _ in range(A_)]
-            def run_multi(n):
-                done = 0
-                while done < n:
-                    c = min(n - done, 2_000)
-                    for t_, st_ in zip(trs, streams):
-                        with torch.cuda.stream(st_):
-                            t_.train_steps(buf, c, BATCH, return_losses=False, graph_unroll=args.unroll)
-                    done += c
-            torch.cuda.synchronize()
-            run_multi(2_000)
+            group = ia.SeedGroup(trs)
+            group.train_steps(buf, 2_000, BATCH, graph_unroll=args.unroll)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             n_multi = 20_000
-            run_multi(n_multi)
+            group.train_steps(buf, n_multi, BATCH, graph_unroll=args.unroll)
             torch.cuda.synchronize()
             dt_m = time.perf_counter() - t1
             out["agents_per_gpu"] = {"agents": A_, "value": A_ * n_multi / dt_m, "unit": "steps/s",

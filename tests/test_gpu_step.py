@@ -334,3 +334,22 @@ def test_shapes_beyond_the_goldens_vs_oracle(gh, S, A, H, B, det, drop, E, mode)
             tol = 2e-6 if mode == "fp32" else 2e-3
             assert (diff > tol).mean() < 1e-4, f"{name}/{k}: {(diff > tol).mean():.2e} of elements off"
             assert diff.max() < K * 3e-4 + tol, f"{name}/{k}: max {diff.max():.3e}"
+
+
+def test_seed_group_matches_separate_runs(gh):
+    """Several seeds on one GPU (separate streams, shared buffer) = the same seeds run alone, bit for bit."""
+    import iqlpref_amd as ia
+    d, hyper, data, nets = helpers.load_traj("traj_antmaze", "bf16")
+    B = hyper["batch"]
+    buf = gh.make_buffer(hyper, data)
+    seeds = (3, 4, 5)
+    alone = [gh.make_trainer(hyper, nets, "bf16", seed=s) for s in seeds]
+    want = [t.train_steps(buf, 37, B, graph_unroll=4).cpu().numpy() for t in alone]
+    group = ia.SeedGroup([gh.make_trainer(hyper, nets, "bf16", seed=s) for s in seeds], chunk=10)
+    got = group.train_steps(buf, 37, B, return_losses=True, graph_unroll=4)
+    group.synchronize()
+    for w, g, ta, tg in zip(want, got, alone, group.trainers):
+        np.testing.assert_array_equal(w, g.cpu().numpy())
+        for (k, va), (_, vb) in zip(ta.actor.state_dict().items(), tg.actor.state_dict().items()):
+            assert torch.equal(va, vb), k
+    assert not np.array_equal(want[0], want[1])  # different seeds sample different batches
