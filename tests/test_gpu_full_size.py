@@ -1,0 +1,111 @@
+"""BASELINE.json's full sizes (1M-transition buffer, batch 256, hidden 256): the oracle cannot
+step through these in seconds, so the HIP path is checked through size-independent properties
+-- bit-exact gathers against numpy on samples and on the extremes, the Philox index stream,
+run-to-run determinism, graph == eager, chunk invariance of the relabel forward, order
+statistics of the CVaR tail mean -- plus the oracle itself on the first steps.  -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import iql_oracle as orc
+from oracle import philox
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+S, A, H, B, N = 29, 8, 256, 256, 1_000_000
+
+
+@pytest.fixture(scope="module")
+def big():
+    import bench
+    import iqlpref_amd as ia
+    data = bench.synth_dataset(7, N)
+    buf = ia.ReplayBuffer(S, A, N, DEV)
+    buf.load_d4rl_dataset(data)
+    return ia, bench, data, buf
+
+
+def test_full_size_buffer_gather_and_index_stream(big):
+    ia, bench, data, buf = big
+    assert buf._size == N and buf._pointer == N
+    rng = np.random.default_rng(0)
+    idx = np.concatenate([[0, N - 1, N - 1, 0], rng.integers(0, N, 4092)]).astype(np.int64)
+    got = buf.sample(len(idx), indices=torch.from_numpy(idx).to(DEV))
+    for g, w in zip(got, orc.gather_batch(data, idx)):
+        np.testing.assert_array_equal(g.cpu().numpy(), w)  # bit exact
+    # whole-buffer checksum of checksums: every stored word equals the source (xor of the bit images)
+    for view, key in ((buf._states, "observations"), (buf._actions, "actions"), (buf._next_states, "next_observations")):
+        dev = view.contiguous().view(torch.int32)
+        ref = torch.from_numpy(np.ascontiguousarray(data[key])).view(torch.int32)
+        assert int(dev.sum(dtype=torch.int64)) == int(ref.sum(dtype=torch.int64))
+    # on-device Philox indices == oracle stream at N = 1M (unbiased range, in bounds)
+    torch.manual_seed(123)
+    for call in range(3):
+        b = buf.sample(B)
+        ix = philox.sample_indices(123, call, B, N)
+        assert ix.min() >= 0 and ix.max() < N
+        np.testing.assert_array_equal(b[0].cpu().numpy(), data["observations"][ix])
+        np.testing.assert_array_equal(b[4].cpu().numpy()[:, 0], data["terminals"][ix])
+
+
+def test_full_size_training_is_deterministic_and_matches_the_oracle_at_the_start(big):
+    ia, bench, data, buf = big
+    K = 300
+    runs = []
+    for unroll in (50, 0, 50):
+        tr = bench.build_trainer(ia, torch, DEV, 5, "bf16")
+        runs.append((tr, tr.train_steps(buf, K, B, graph_unroll=unroll).cpu().numpy()))
+    np.testing.assert_array_equal(runs[0][1], runs[2][1])  # same seed, same bits
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])  # hipGraph replay == eager launches
+    for (k, va), (_, vb) in zip(runs[0][0].qf.state_dict().items(), runs[1][0].qf.state_dict().items()):
+        assert torch.equal(va, vb), k
+    assert np.isfinite(runs[0][1]).all()
+    # the oracle on the same index stream for the first steps (bf16 arithmetic of the reference)
+    torch.manual_seed(5)
+    q, v, a = ia.TwinQ(S, A), ia.ValueFunction(S), ia.GaussianPolicy(S, A, 1.0)
+    sd = lambda m: {k: t.detach().numpy() for k, t in m.state_dict().items()}
+    o = orc.IQLOracle(sd(q), sd(v), sd(a), mode="bf16", **bench.HYPER)
+    for t in range(3):
+        out = o.train(orc.gather_batch(data, philox.sample_indices(5, t, B, N)))
+        np.testing.assert_allclose(runs[0][1][t], [out["value_loss"], out["q_loss"], out["actor_loss"]],
+                                   rtol=6e-3)  # bf16 tolerance of tests/test_gpu_step.py
+
+
+def test_full_size_relabel_properties(big):
+    ia, bench, data, buf = big
+    from iqlpref_amd.relabel import cvar_tail_mean_device
+    torch.manual_seed(0)
+    x = torch.cat([buf._states, buf._actions], 1)  # [1M, 37]
+    ws = [torch.randn(37, 256, device=DEV) * 0.1, torch.randn(256, 256, device=DEV) * 0.05,
+          torch.randn(256, 1, device=DEV) * 0.05]
+    bs = [torch.randn(256, device=DEV) * 0.1, torch.randn(256, device=DEV) * 0.1, torch.randn(1, device=DEV)]
+    whole = ia.mlp_forward_f32(ws, bs, x, w_in_out=True)
+    assert whole.shape == (N, 1) and torch.isfinite(whole).all()
+    # chunk invariance: any split of the rows gives the same bits
+    parts = torch.cat([ia.mlp_forward_f32(ws, bs, x[a:b], w_in_out=True)
+                       for a, b in ((0, 1), (1, 4097), (4097, 600_001), (600_001, N))])
+    assert torch.equal(whole, parts)
+    # a sample of rows against fp64 numpy
+    rows = np.random.default_rng(1).integers(0, N, 512)
+    h = x[rows].double().cpu().numpy()
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        h = h @ w.double().cpu().numpy() + b.double().cpu().numpy()
+        if i < 2:
+            h = np.maximum(h, 0)
+    np.testing.assert_allclose(whole[rows].cpu().numpy(), h, rtol=2e-5, atol=2e-6)
+    # CVaR tail mean over a [20, 1M] prediction matrix: order statistics
+    Sn = 20
+    preds = torch.randn(Sn, N, device=DEV)
+    preds[3] = preds[7]  # ties
+    full = cvar_tail_mean_device(preds, Sn)
+    np.testing.assert_allclose(full.cpu().numpy(), preds.mean(0).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    one = cvar_tail_mean_device(preds, 1)
+    assert torch.equal(one, preds.min(0).values)  # n_tail = 1: the minimum, exactly
+    prev = one
+    for n_tail in (2, 5, 19):
+        cur = cvar_tail_mean_device(preds, n_tail)
+        assert (cur >= prev - 1e-6).all()  # the tail mean grows with the tail
+        prev = cur
+    srt = preds[:, :4096].sort(0).values[:5].mean(0)
+    np.testing.assert_allclose(cvar_tail_mean_device(preds, 5)[:4096].cpu().numpy(), srt.cpu().numpy(),
+                               rtol=1e-5, atol=1e-6)
