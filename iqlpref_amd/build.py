@@ -24,8 +24,11 @@ def build(force=False, verbose=True, stamps=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out = LIB.replace(".so", "_stamps.so") if stamps else LIB
+    # kernarg preload: the first 16 kernarg dwords (the descriptor pointers) arrive in SGPRs with
+    # the wave instead of through a dependent s_load at the top of every kernel (+1.3 % measured)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wno-unused-value", "-mllvm", "-amdgpu-kernarg-preload-count=16",
+           "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
     if stamps:
         cmd.insert(1, "-DIQL_STAMPS")
     if verbose:
