@@ -310,18 +310,20 @@ __device__ __forceinline__ void write_adam_coef(const TrainerDesc &D, const DevA
 template <bool BF16, int H>
 __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__ Dp,
                                                  const DevArgs *__restrict__ Ap,
-                                                 const DevCtr *__restrict__ Cp) {
+                                                 const DevCtr *__restrict__ Cp, const int nsl_,
+                                                 const int nfwd_) {
   using P = Prec<BF16>;
   using T = typename P::T;
   // blocks are dealt round-robin over the 8 XCDs: keep all slabs of one network on one
   // XCD so its weights are fetched into that L2 once (speed only, never correctness).
   // Job j (evaluation j < nfwd, or the spare job nfwd) lives on XCD j & 7, round j >> 3.
+  // (nsl_ = B / 16 and nfwd_ arrive as preloaded kernel arguments: the job index, and with it
+  // the address of this work-group's FwdNet, must not wait for a first descriptor load)
   const TrainerDesc &D = *Dp;
-  const int nsl_ = D.B / SLAB;
   const int idx_ = blockIdx.x >> 3;
   const int fnet = (idx_ / nsl_) * 8 + (blockIdx.x & 7), slab = idx_ % nsl_;
-  if (fnet > D.nfwd) return;
-  if (fnet == D.nfwd) {
+  if (fnet > nfwd_) return;
+  if (fnet == nfwd_) {
     // spare XCD slot: one thread prepares this step's Adam coefficients for k_update
     if (slab == 0 && threadIdx.x == 0) {
       write_adam_coef(D, *Ap, Cp->ctr[0] + 1, const_cast<AdamCoef *>(&Cp->coef));
@@ -511,7 +513,7 @@ __device__ __forceinline__ void loss_terms(const TrainerDesc &D, int net, const 
 // ========================================================================
 template <bool BF16, int H>
 __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp, DevCtr *__restrict__ Cp,
-                                              const int blk, char *smem) {
+                                              const int blk, char *smem, const int nslab, const int ntrain) {
   using K = KCfg<BF16, H>;
   using P = Prec<BF16>;
   using T = typename P::T;
@@ -524,13 +526,13 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   // Job j = 2 net + sub lives on XCD j & 7, round j >> 3 (E = 2: XCD x serves network x / 2).
   // SPLIT == 2: sub = which half of W2^T (each L2 fetches only the half its work-groups
   // stream); SPLIT == 1: sub = slab parity.
+  // (nslab, ntrain: preloaded kernel arguments, see k_forward)
   const TrainerDesc &D = *Dp;
-  const int nslab = D.B / SLAB;
   const int per_round = SPLIT == 2 ? nslab : (nslab + 1) / 2;
   const int idx_ = blk >> 3;
   const int job = (idx_ / per_round) * 8 + (blk & 7), rest = idx_ % per_round;
   const int net = job >> 1, sub = job & 1;
-  if (net >= D.ntrain) return;
+  if (net >= ntrain) return;
   const int half = SPLIT == 2 ? sub : 0;
   const int slab = SPLIT == 2 ? rest : ((rest << 1) | sub);
   if (slab >= nslab) return;
@@ -1225,9 +1227,10 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 // ------------------------------------------------------------------------
 template <bool BF16, int H>
 __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict__ Dp,
-                                                  const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp) {
+                                                  const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
+                                                  const int nslab, const int ntrain) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  backward_body<BF16, H>(Dp, Cp, (int)blockIdx.x, smem);
+  backward_body<BF16, H>(Dp, Cp, (int)blockIdx.x, smem, nslab, ntrain);
 }
 
 template <bool BF16>
@@ -1295,7 +1298,8 @@ hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD
                           const DevCtr *c, hipStream_t st) {
   const int grid = 8 * ((D.nfwd + 1 + 7) / 8) * (D.B / SLAB);  // nfwd evaluations + the spare job
   const size_t sm = fwd_smem_bytes(bf16, D.H, D.k1max);
-#define CALL(BF, HH) hipLaunchKernelGGL((k_forward<BF, HH>), dim3(grid), dim3(256), sm, st, dD, a, c)
+#define CALL(BF, HH) \
+  hipLaunchKernelGGL((k_forward<BF, HH>), dim3(grid), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.nfwd)
   DISPATCH_H(bf16, D.H, CALL);
 #undef CALL
   return hipGetLastError();
@@ -1304,7 +1308,8 @@ hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *d
                            DevCtr *c, hipStream_t st) {
   const int grid = 8 * ((2 * D.ntrain + 7) / 8) * (D.H >= 128 ? D.B / SLAB : (D.B / SLAB + 1) / 2);
   const size_t sm = bwd_smem_bytes(bf16, D.H);
-#define CALL(BF, HH) hipLaunchKernelGGL((k_backward<BF, HH>), dim3(grid), dim3(256), sm, st, dD, a, c)
+#define CALL(BF, HH) \
+  hipLaunchKernelGGL((k_backward<BF, HH>), dim3(grid), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain)
   DISPATCH_H(bf16, D.H, CALL);
 #undef CALL
   return hipGetLastError();
