@@ -193,13 +193,13 @@ def main():
         # HIP events on the launch stream give each kernel's share of a step; the shares are
         # scaled so that the three launches tile the measured device time per step, which is how
         # rocprofv3 --kernel-trace attributes the timeline (dispatch to completion, back to back):
-        # profiles/r01_d_kernel_stats.csv is the cross-check
+        # profiles/r01_e_kernel_stats.csv is the cross-check
         ev_us = [avg[k] * 1e3 for k in range(3)]
         scale = step_us_dev / sum(ev_us) if sum(ev_us) > 0 else 1.0
         upd_us = ev_us[2] * scale
         achieved = upd_bytes / (upd_us * 1e-6) / 1e9  # GB/s of k_update
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_d_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_e_traffic.json")
         if os.path.exists(tpath):  # PMC pass (separate rocprofv3 --pmc runs), bytes per launch of k_update
             with open(tpath) as f:
                 traffic = json.load(f).get("k_update_bytes_per_launch")
