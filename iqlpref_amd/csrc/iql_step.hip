@@ -50,6 +50,19 @@ constexpr int SLAB = 16;  // batch rows per work-group (one MFMA M tile)
   } while (0)
 #endif
 
+// Descriptor fields that a kernel first touches in its middle are fetched there, by a scalar
+// load that misses the scalar cache (~0.5 us each, serial).  pin_s() is a use at the top of the
+// kernel: the loads join the first batch and the values stay in SGPRs.
+template <class T>
+__device__ __forceinline__ void pin_s(T v) {
+  if constexpr (sizeof(T) == 8) {
+    asm volatile("" ::"s"(__builtin_bit_cast(uint64_t, v)));
+  } else {
+    static_assert(sizeof(T) == 4, "pin_s: 4- or 8-byte values");
+    asm volatile("" ::"s"(__builtin_bit_cast(uint32_t, v)));
+  }
+}
+
 template <bool BF16, int H>
 struct KCfg {
   using P = Prec<BF16>;
@@ -163,6 +176,9 @@ __device__ __forceinline__ void mlp_slab(const FwdNet &N, const TrainerDesc &D, 
   float *red = reinterpret_cast<float *>(h2 + SLAB * HP);   // [4][2][64][4]
 
   STAMP(0, 0);
+  // everything the epilogues need from the descriptors joins the first batch of scalar loads
+  pin_s(D.hT), pin_s(D.BP), pin_s(N.train_slot), pin_s(N.dropout), pin_s(N.b3), pin_s(N.out_dim);
+  pin_s(N.out_col), pin_s(N.tanh_out), pin_s(N.out_pad), pin_s(out), pin_s(out_stride), pin_s(n_valid);
   // the input rows first: loads return in order, so the gather must not queue behind
   // the 160 KB of weight fragments requested next
   issue();
@@ -552,6 +568,15 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   float *rowsum = gstd + SLAB * 32;                            // [16]
 
   if (blk == 0 && tid == 0) Cp->ctr[1] = Cp->ctr[0] + 1;
+  T *const g_dz1T = reinterpret_cast<T *>(D.dz1T), *const g_dz2T = reinterpret_cast<T *>(D.dz2T);
+  T *const g_dz3T = reinterpret_cast<T *>(D.dz3T);
+  float *const g_lsp = D.lsp, *const g_lossp = D.lossp;
+  const int opmax = D.opmax, n_act = D.A;
+  const bool drop_on = D.has_dropout && net == D.net_a;
+  const float drop_scale = D.drop_scale;
+  const bool is_gauss_actor = net == D.net_a && !D.deterministic;
+  pin_s(g_dz1T), pin_s(g_dz2T), pin_s(g_dz3T), pin_s(g_lsp), pin_s(g_lossp), pin_s(opmax), pin_s(n_act);
+  pin_s(drop_scale), pin_s((int)drop_on), pin_s((int)is_gauss_actor);
   STAMP(1, 0);
 
   // ---- the loss inputs first: loads return in order, these must not queue behind the
@@ -617,23 +642,23 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     for (int j = 0; j < N.out_dim; ++j) s += lterm[j * SLAB + tid];
     rowsum[tid] = s;
   }
-  if (half == 0 && net == D.net_a && !D.deterministic && tid >= 64 && tid < 64 + D.A) {
+  if (half == 0 && is_gauss_actor && tid >= 64 && tid < 64 + n_act) {
     const int j = tid - 64;
     float s = 0.f;
 #pragma unroll
     for (int rr = 0; rr < SLAB; ++rr) s += gstd[j * SLAB + rr];
-    stg(D.lsp + (size_t)slab * D.A + j, s);
+    stg(g_lsp + (size_t)slab * n_act + j, s);
   }
   // d(out), feature-major, for the layer-3 weight gradient
   for (int e = tid; half == 0 && e < N.out_dim * SLAB; e += 256) {
     const int j = e / SLAB, rr = e - j * SLAB;
-    stg(reinterpret_cast<T *>(D.dz3T) + (size_t)net * D.opmax * BP + fidx<P>(j, slab * SLAB + rr, nkb),
+    stg(g_dz3T + (size_t)net * opmax * BP + fidx<P>(j, slab * SLAB + rr, nkb),
         P::from_f32(dz3[j * SLAB + rr]));
   }
 
   // ---- dZ2 = (dZ3 W3) * relu'(h2)   (VALU: K = out_dim <= 32) ----
   if (tid < H) {
-    T *dst = reinterpret_cast<T *>(D.dz2T) + (size_t)net * H * BP;
+    T *dst = g_dz2T + (size_t)net * H * BP;
     float s[SLAB];
 #pragma unroll
     for (int rr = 0; rr < SLAB; ++rr) s[rr] = 0.f;
@@ -655,7 +680,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
       for (int i = 0; i < 4; ++i) {
         const int rr = 4 * g4 + i;
         float sv = P::round(s[rr]);
-        if (D.has_dropout && net == D.net_a) sv = P::round(sv * D.drop_scale);
+        if (drop_on) sv = P::round(sv * drop_scale);
         outv[i] = h2v[rr] > 0.f ? sv : 0.f;
         dz2s[rr * HP + c2] = P::from_f32(outv[i]);
       }
@@ -668,7 +693,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     float s = 0.f;
 #pragma unroll
     for (int rr = 0; rr < SLAB; ++rr) s += rowsum[rr];
-    stg(D.lossp + net * nslab + slab, s);
+    stg(g_lossp + net * nslab + slab, s);
   }
 
   // ---- dZ1 = (dZ2 W2) * relu'(h1)   (MFMA, B operand = transposed copy) ----
@@ -689,10 +714,10 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float s = P::round(acc[jj][i]);
-        if (D.has_dropout && net == D.net_a) s = P::round(s * D.drop_scale);
+        if (drop_on) s = P::round(s * drop_scale);
         outv[i] = h1v[jj][i] > 0.f ? s : 0.f;
       }
-      store4T<BF16>(reinterpret_cast<T *>(D.dz1T) + (size_t)net * H * BP +
+      store4T<BF16>(g_dz1T + (size_t)net * H * BP +
                         fidx<P>(col, slab * SLAB + 4 * q, nkb), outv);
     }
   }
@@ -879,6 +904,11 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       it.group == 0 ? coef.neg_step[0] : (it.group == 1 ? coef.neg_step[1] : coef.neg_step[2]);
   const bool has_target = it.has_target != 0;
   const int nk = BP / P::KM;
+  // descriptor / item fields of the Adam and store phases: fetched with the first batch
+  pin_s(D.params), pin_s(D.exp_avg), pin_s(D.exp_avg_sq), pin_s(D.target), pin_s(D.grads), pin_s(D.tau);
+  pin_s(it.off_w), pin_s(it.toff_w), pin_s(it.off_b), pin_s(it.toff_b), pin_s(it.wc), pin_s(it.tc);
+  pin_s(it.w2ct), pin_s(it.Xsrc), pin_s(it.Zsrc), pin_s(Kw), pin_s(neg_step);
+  pin_s(coef.one_m_b1), pin_s(coef.b2), pin_s(coef.one_m_b2), pin_s(coef.bc2_sqrt), pin_s(coef.eps);
 
   if (L == 0) {
     // =========== layer 1: a strip of 32 out-features x ALL in-features ===========

@@ -28,7 +28,10 @@ tr = bench.build_trainer(ia, torch, dev, 1, prec)
 tr.train_steps(buf, 200, bench.BATCH, return_losses=False, graph_unroll=0)
 dbg = torch.zeros((3, 512, 8, 2), dtype=torch.int64, device=dev)
 _lib.check(lib.iqlhip_trainer_set_debug(tr._handle, C.c_void_p(dbg.data_ptr())))
-tr.train_steps(buf, 1, bench.BATCH, return_losses=False, graph_unroll=0)
+# STAMP_GRAPH=n: n steps replayed as one hipGraph (the stamps of the LAST step survive): kernel
+# starts in steady state instead of after a host-side gap
+_g = int(os.environ.get("STAMP_GRAPH", "0"))
+tr.train_steps(buf, max(_g, 1), bench.BATCH, return_losses=False, graph_unroll=_g)
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().astype(np.float64)
 names = ["k_forward", "k_backward", "k_update"]
