@@ -193,6 +193,9 @@ __device__ __forceinline__ void mlp_slab(const FwdNet &N, const TrainerDesc &D, 
     bias1[jj] = ldg(N.b1 + 16 * (wave * TPW + jj) + r);
     bias2[jj] = ldg(N.b2 + 16 * (wave * TPW + jj) + r);
   }
+  float bias3[2];  // output-layer bias of this lane's column(s), clamped (used for col < out_dim)
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) bias3[jt] = ldg(N.b3 + (16 * jt + r < N.out_dim ? 16 * jt + r : N.out_dim - 1));
   uint4 w1[K::NK1][TPW], w2[K::NKC][TPW], w3[K::NK3][2];
   const T *W1 = reinterpret_cast<const T *>(N.w1c);
   const T *W2 = reinterpret_cast<const T *>(N.w2c);
@@ -302,7 +305,7 @@ __device__ __forceinline__ void mlp_slab(const FwdNet &N, const TrainerDesc &D, 
         for (int w = 1; w < 4; ++w) s += *reinterpret_cast<f32x4 *>(red + ((w * 2 + jt) * 64 + lane) * 4);
         const int col = 16 * jt + r;
         if (col < N.out_dim) {
-          const float bias = P::round(ldg(N.b3 + col));
+          const float bias = P::round(bias3[jt]);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             float v = P::round(s[i] + bias);
