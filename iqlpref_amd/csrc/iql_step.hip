@@ -1,21 +1,30 @@
 // IQL optimisation step for MI355X (gfx950): three kernels per step.
 //
-//   k_forward   7 MLP evaluations x B/16 row slabs, one work-group each:
-//               gather the slab's transitions from the packed replay rows,
-//               3 Linear layers on MFMA (activations staged in LDS, weights
-//               streamed from L2 straight into B fragments), hidden activations
-//               of the trained nets stored feature-major for the backward GEMMs.
-//   k_backward  4 trained nets x B/16 slabs: loss terms (expectile, TD, AWR),
-//               d(out), dZ2 (VALU outer product), dZ1 (MFMA), all stored
+//   k_forward   (2E+3) MLP evaluations x B/16 row slabs, one work-group each (E critics; E = 2
+//               is the reference's TwinQ): the slab's transitions (prefetched by the previous
+//               k_update, else gathered from the packed replay rows), 3 Linear layers on
+//               MFMA (activations staged in LDS, weights streamed from L2 straight into B
+//               fragments), hidden activations of the trained nets stored feature-major for
+//               the backward GEMMs.  A spare job writes the step's Adam coefficients.
+//   k_backward  (E+2) trained nets x B/16 slabs x 2 halves of W2^T: loss terms (expectile,
+//               TD, AWR), d(out), dZ2 (VALU outer product), dZ1 (MFMA), all stored
 //               feature-major; per-slab loss partial sums.
-//   k_update    weight-gradient GEMMs (K = batch) fused with Adam, the
-//               compute-precision weight copies, and the Polyak target update;
-//               the gradient tile never leaves registers.
+//   k_update    weight-gradient GEMMs (K = batch) fused with Adam, the compute-precision
+//               weight copies and the Polyak target update: 64x32 tiles for the H-wide
+//               layers, 16-row strips with a flat state stream for layer 1; idle slots of
+//               the XCD-major item table prefetch the next step's batch.
 //
-// Every kernel is latency-bound (one 16-row slab per work-group, ~100 work-groups
-// on 256 CUs), so each one issues ALL of its global loads (weight fragments,
-// optimizer state, saved activations) before the first dependent instruction
-// and only then walks its dependency chain.
+// Every kernel is a latency chain (one 16-row slab / one tile per work-group, 100-260
+// work-groups on 256 CUs).  Rules the code follows, each measured:
+//   * every global load a work-group will need is requested before its first dependent
+//     instruction, in the order the values are consumed (loads return in order);
+//   * load phases are branch-free: clamped always-valid addresses, the guard moves to the use
+//     (a guarded load is a branch followed by s_waitcnt vmcnt(0)); wave-uniform conditions are
+//     scalar; the first k-chunk is straight-line (a loop pre-header drains pending loads);
+//   * descriptor scalars used later are pinned at entry (pin_s) so that no scalar load misses
+//     in the middle of a kernel;
+//   * no runtime-indexed register arrays, no flat (generic) accesses, descriptors in device
+//     memory rather than the kernarg segment.
 //
 // Reference: /root/reference/algorithms/offline/iql.py:581-662 (order of
 // operations), :404-405 (expectile), :127-129 (Polyak), torch.optim.Adam
