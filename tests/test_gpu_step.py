@@ -353,3 +353,27 @@ def test_seed_group_matches_separate_runs(gh):
         for (k, va), (_, vb) in zip(ta.actor.state_dict().items(), tg.actor.state_dict().items()):
             assert torch.equal(va, vb), k
     assert not np.array_equal(want[0], want[1])  # different seeds sample different batches
+
+
+def test_trainer_lifecycle_does_not_leak(gh):
+    """Create / step / destroy many trainers: workspace, graphs, streams and events are released."""
+    import gc
+    d, hyper, data, nets = helpers.load_traj("traj_antmaze", "bf16")
+    buf = gh.make_buffer(hyper, data)
+    torch.cuda.synchronize()
+    gc.collect()
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    ref = None
+    for i in range(40):
+        tr = gh.make_trainer(hyper, nets, "bf16", seed=1)
+        out = tr.train_steps(buf, 9, hyper["batch"], graph_unroll=4).cpu().numpy()
+        if ref is None:
+            ref = out
+        np.testing.assert_array_equal(out, ref)  # a fresh trainer always starts from the same state
+        del tr
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB not returned after 40 trainers"
