@@ -1099,6 +1099,63 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     return;
   }
 
+  // ---- 2. dW^T tile on MFMA: A = layer input X^T, B = dZ^T (fragment-major) ----
+  const T *Xsrc = reinterpret_cast<const T *>(it.Xsrc);
+  const T *Zsrc = reinterpret_cast<const T *>(it.Zsrc);
+  // wave (wo, wi) = (wave >> 1, wave & 1): in-feature tile wi x out-feature tiles 2wo, 2wo+1
+  const int wo = wave >> 1, wi = wave & 1;
+  const int ib = i0 + 16 * wi, ob = o0 + 32 * wo;
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  float bsum[2] = {0.f, 0.f};
+  const bool do_bias = i0 == 0;
+  const bool wave_bias = do_bias && wi == 0;
+  // Branch-free operand stream: in-features always exist here (Idim = H), out-feature tiles
+  // beyond Opad (layer 3: one tile) re-read the last tile -- their products land in tile rows
+  // that are never stored -- and k-steps beyond nk re-read the last one and are skipped by the
+  // (scalar) guard around the MFMA only.
+  const int ntile_o = Opad >> 4;
+  int ot[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) ot[b] = (ob >> 4) + b < ntile_o ? (ob >> 4) + b : ntile_o - 1;
+  // Operand fragments are requested FIRST, the optimiser state behind them: the MFMAs (and the
+  // LDS hand-over to the row-ordered Adam pass) then start as soon as the fragments are in, while
+  // the state is still streaming (+0.8 % measured).  First chunk straight-line: a loop
+  // pre-header would drain every pending load.
+  auto load_frags = [&](const int k0, uint4(&xf)[UKC], uint4(&zf)[UKC][2]) {
+#pragma unroll
+    for (int ks = 0; ks < UKC; ++ks) {
+      const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
+      xf[ks] = ldg16(Xsrc + frag_off<P>(ib >> 4, kk, nk, lane));
+#pragma unroll
+      for (int b = 0; b < 2; ++b) zf[ks][b] = ldg16(Zsrc + frag_off<P>(ot[b], kk, nk, lane));
+    }
+  };
+  auto mma_frags = [&](const int k0, const uint4(&xf)[UKC], const uint4(&zf)[UKC][2]) {
+#pragma unroll
+    for (int ks = 0; ks < UKC; ++ks) {
+      if (k0 + ks < nk) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (wave_bias) {  // bias gradient = row sums of dZ^T (this lane: its out-feature, 1/4 of K)
+            if constexpr (BF16) {
+              const uint32_t w[4] = {zf[ks][b].x, zf[ks][b].y, zf[ks][b].z, zf[ks][b].w};
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                bsum[b] += bf2f((uint16_t)(w[i] & 0xffff)) + bf2f((uint16_t)(w[i] >> 16));
+            } else {
+              const float4 f = __builtin_bit_cast(float4, zf[ks][b]);
+              bsum[b] += (f.x + f.y) + (f.z + f.w);
+            }
+          }
+          P::mma(xf[ks], zf[ks][b], acc[b]);
+        }
+      }
+    }
+  };
+  uint4 xf0[UKC], zf0[UKC][2];
+  load_frags(0, xf0, zf0);
+  __builtin_amdgcn_sched_barrier(0);
+
   // ---- 1. optimiser state, row order: thread -> (row tr + 16 pass, columns 4 tc .. +3) ----
   const int tr = tid / UTPR, tc4 = (tid % UTPR) * 4;
   float pw[UNP][4], mw[UNP][4], vw[UNP][4], tw[UNP][4];  // statically indexed only (registers)
@@ -1126,7 +1183,6 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   }
   // biases: every thread loads (clamped index, dummy target), threads < 64 of the i0 = 0 tile use them
   float pb, mb, vb, tb;
-  const bool do_bias = i0 == 0;
   {
     const int ob_ = o0 + (tid & (UTO - 1)) < Odim ? o0 + (tid & (UTO - 1)) : Odim - 1;
     const int64_t eb = it.off_b + ob_;
@@ -1135,58 +1191,14 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   }
   STAMP(2, 1);
 
-  // ---- 2. dW^T tile on MFMA: A = layer input X^T, B = dZ^T (fragment-major) ----
-  const T *Xsrc = reinterpret_cast<const T *>(it.Xsrc);
-  const T *Zsrc = reinterpret_cast<const T *>(it.Zsrc);
-  // wave (wo, wi) = (wave >> 1, wave & 1): in-feature tile wi x out-feature tiles 2wo, 2wo+1
-  const int wo = wave >> 1, wi = wave & 1;
-  const int ib = i0 + 16 * wi, ob = o0 + 32 * wo;
-  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  float bsum[2] = {0.f, 0.f};
-  const bool wave_bias = do_bias && wi == 0;
-  // Branch-free operand stream: in-features always exist here (Idim = H), out-feature tiles
-  // beyond Opad (layer 3: one tile) re-read the last tile -- their products land in tile rows
-  // that are never stored -- and k-steps beyond nk re-read the last one and are skipped by the
-  // (scalar) guard around the MFMA only.
-  const int ntile_o = Opad >> 4;
-  int ot[2];
-#pragma unroll
-  for (int b = 0; b < 2; ++b) ot[b] = (ob >> 4) + b < ntile_o ? (ob >> 4) + b : ntile_o - 1;
-  // (the first chunk is straight-line code: a loop would make the compiler drain every pending
-  // load -- the optimiser state -- in its pre-header before the operand loads are issued)
-  auto chunk = [&](const int k0) {
-    uint4 xf[UKC], zf[UKC][2];
-#pragma unroll
-    for (int ks = 0; ks < UKC; ++ks) {
-      const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
-      xf[ks] = ldg16(Xsrc + frag_off<P>(ib >> 4, kk, nk, lane));
-#pragma unroll
-      for (int b = 0; b < 2; ++b) zf[ks][b] = ldg16(Zsrc + frag_off<P>(ot[b], kk, nk, lane));
-    }
-#pragma unroll
-    for (int ks = 0; ks < UKC; ++ks) {
-      if (k0 + ks < nk) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          if (wave_bias) {  // bias gradient = row sums of dZ^T (this lane: its out-feature, 1/4 of K)
-            if constexpr (BF16) {
-              const uint32_t w[4] = {zf[ks][b].x, zf[ks][b].y, zf[ks][b].z, zf[ks][b].w};
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-                bsum[b] += bf2f((uint16_t)(w[i] & 0xffff)) + bf2f((uint16_t)(w[i] >> 16));
-            } else {
-              const float4 f = __builtin_bit_cast(float4, zf[ks][b]);
-              bsum[b] += (f.x + f.y) + (f.z + f.w);
-            }
-          }
-          P::mma(xf[ks], zf[ks][b], acc[b]);
-        }
-      }
-    }
-  };
-  chunk(0);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_frags(0, xf0, zf0);
 #pragma unroll 1
-  for (int k0 = UKC; k0 < nk; k0 += UKC) chunk(k0);
+  for (int k0 = UKC; k0 < nk; k0 += UKC) {
+    uint4 xf[UKC], zf[UKC][2];
+    load_frags(k0, xf, zf);
+    mma_frags(k0, xf, zf);
+  }
   // C/D layout: lane (r, q) of acc[b] holds dW[ob + 16 b + r][ib + 4 q + k]
 #pragma unroll
   for (int b = 0; b < 2; ++b)
