@@ -1266,7 +1266,8 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     // thread -> in-feature i0 + (tid >> 4) + 16 pass, out-features o0 + 4 (tid & 15) .. +3
 #pragma unroll
     for (int ps = 0; ps < UTI / 16; ++ps) {
-      const int il = (tid >> 4) + 16 * ps, o4 = (tid & 15) * 4;
+      // consecutive lanes read consecutive in-features of one tile row: conflict-free LDS reads
+      const int il = tid & (UTI - 1), o4 = ((tid >> 5) + 8 * ps) * 4;
       float pv4[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) pv4[k] = tile[(o4 + k) * ULD + il];
