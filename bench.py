@@ -8,11 +8,23 @@ replay buffer (BASELINE.json configs[1], antmaze-medium-diverse-v2 shapes).
 One step = ReplayBuffer.sample + ImplicitQLearning.train (V/Q/actor updates,
 Polyak, cosine LR) = reference iql.py:1535-1536.  Every rank trains its own seed
 on its own synthetic dataset (no data-path collective; the only collective is
-the final all-gather of the per-rank metric record).  Rank 0 prints ONE JSON line.
+the all-gather of the per-rank metric record).  Rank 0 prints ONE JSON line.
+
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N rank
+processes itself (one per GPU, RCCL), before anything touches a GPU -- the
+reference's process-per-GPU model (ensemble_sweeps/launch.sh:84-94).
+
+Timing: W untimed warm-up steps, then blocks of EXACTLY K steps, each replayed
+as one hipGraph of K steps (unroll = min(--unroll, K)) and bracketed by
+barrier + synchronize on both sides.  The block is repeated until >= 0.25 s of
+timed work has accumulated; `ms_per_step` is the median block (max over ranks)
+divided by K, `value` = N * K / that block time.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,6 +40,13 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 
 S_DIM, A_DIM, HIDDEN, BATCH, N_ROWS = 29, 8, 256, 256, 1_000_000
 HYPER = dict(beta=10.0, iql_tau=0.9, discount=0.99, tau=0.005, max_steps=1_000_000)
+
+# The reference itself (algorithms/offline/iql.py, stub-imported, device="cpu", bf16 autocast,
+# eager) timed in the build container during the survey: BASELINE.md section 2.  The Python
+# reference cannot travel to the GPU box, so this figure is carried, not re-measured.
+REFERENCE_CPU = {"value": 125.3, "unit": "steps/s", "cores": 8, "kind": "reference",
+                 "where": "build container (8 vCPU Xeon @ 2.1 GHz, torch 2.10 CPU), not this box",
+                 "source": "BASELINE.md section 2 (S=29 A=8 B=256, N=1M, 300 timed steps)"}
 
 
 def synth_dataset(seed, n=N_ROWS):
@@ -82,7 +101,54 @@ def cpu_baseline(data, seconds=12.0):
         cores = os.cpu_count() or 1
     return {"value": steps / dt, "unit": "steps/s", "cores": int(cores), "kind": "port",
             "sample": f"{steps} steps in {dt:.1f} s of oracle/iql_oracle.py (numpy fp32 BLAS), "
-                      f"same shapes (S=29 A=8 H=256 B=256, N=1M)"}
+                      f"same shapes (S=29 A=8 H=256 B=256, N=1M)",
+            "reference_in_container": REFERENCE_CPU}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """Start n rank processes of this script (fresh interpreters: nothing here has touched a
+    GPU yet) and wait for them.  Rank 0 inherits stdout and prints the JSON line."""
+    import torch  # device_count() does not initialise HIP on this image
+
+    backend = os.environ.get("IQL_BENCH_BACKEND", "nccl")
+    visible = torch.cuda.device_count()
+    if backend == "nccl" and visible < n:
+        print(f"bench.py: --gpus {n} but only {visible} GPU(s) are visible; refusing to run fewer "
+              f"ranks than asked for", file=sys.stderr)
+        return 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:  # a dead rank leaves the others in a collective: end them
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
@@ -91,16 +157,22 @@ def main():
     ap.add_argument("--steps", type=int, default=50_000)
     ap.add_argument("--warmup", type=int, default=5_000)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--unroll", type=int, default=50)
+    ap.add_argument("--unroll", type=int, default=50, help="steps per hipGraph (clamped to --steps)")
+    ap.add_argument("--min-timed-s", type=float, default=0.25,
+                    help="the K-step block is repeated until this much timed work has accumulated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ensemble-q", type=int, default=4,
                     help="extra leg (N=1 only): BASELINE configs[4], an E-critic ensemble at batch 1024 "
                          "(same antmaze shapes); 0 disables.  Reported beside `value`, never as it")
     ap.add_argument("--agents-per-gpu", type=int, default=4,
                     help="extra leg (N=1 only): aggregate steps/s of this many independent seeds sharing "
-                         "the GPU on separate streams -- the reference launcher's AGENTS_PER_GPU "
+                         "the GPU -- the reference launcher's AGENTS_PER_GPU "
                          "(ensemble_sweeps/launch.sh:12); 0 disables.  `value` is always 1 seed per GPU")
+    ap.add_argument("--no-relabel", action="store_true", help="skip the reward-relabel leg (N=1 only)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -108,7 +180,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (there is no CPU path)")
@@ -117,6 +189,8 @@ def main():
     backend = os.environ.get("IQL_BENCH_BACKEND", "nccl")
     if backend == "gloo":
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     cdev = device if backend == "nccl" else "cpu"  # where collective payloads live
@@ -133,12 +207,15 @@ def main():
     buf = ia.ReplayBuffer(S_DIM, A_DIM, N_ROWS, device)
     buf.load_d4rl_dataset(data)
     tr = build_trainer(ia, torch, device, seed, args.precision)
+    K = args.steps
+    unroll = max(1, min(args.unroll, K))
+    chunk = max(unroll, 20_000 // unroll * unroll)
 
     def run(n):
         done = 0
         while done < n:
-            c = min(n - done, 20_000)
-            tr.train_steps(buf, c, BATCH, return_losses=False, graph_unroll=args.unroll)
+            c = min(n - done, chunk)
+            tr.train_steps(buf, c, BATCH, return_losses=False, graph_unroll=unroll)
             done += c
 
     def barrier():
@@ -146,38 +223,57 @@ def main():
             dist.barrier()
 
     run(args.warmup)
+    run(K)  # untimed: instantiates the K-step graph the timed blocks replay
     torch.cuda.synchronize()
-    barrier()
+
+    # ---- timed blocks of exactly K steps ----
+    block_s, block_dev_ms = [], []
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record()  # same stream the library launches on (torch's current stream)
-    run(args.steps)
-    ev1.record()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    barrier()
-    dev_ms = ev0.elapsed_time(ev1)
+    reps_cap = 2000
+    while True:
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record()  # same stream the library launches on (torch's current stream)
+        run(K)
+        ev1.record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        barrier()
+        block_s.append(dt)
+        block_dev_ms.append(ev0.elapsed_time(ev1))
+        # every rank must leave the loop in the same iteration: rank 0 decides
+        stop = torch.tensor([1.0 if (sum(block_s) >= args.min_timed_s or len(block_s) >= reps_cap) else 0.0],
+                            dtype=torch.float64, device=cdev)
+        if world > 1:
+            dist.broadcast(stop, src=0)
+        if stop.item() > 0:
+            break
+    reps = len(block_s)
     last = tr.train_steps(buf, 1, BATCH, graph_unroll=0).cpu().numpy()[0]
     if not np.isfinite(last).all():
         raise SystemExit(f"non-finite losses after the timed region: {last}")
 
-    # max over ranks of the wall time
-    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    # max over ranks of every block's wall time, then the median block
+    tblk = torch.tensor(block_s, dtype=torch.float64, device=cdev)
+    recs = None
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        rec = torch.tensor([seed, tr.total_it, *last.tolist()], dtype=torch.float64, device=cdev)
-        recs = [torch.zeros_like(rec) for _ in range(world)]
-        dist.all_gather(recs, rec)  # RCCL: the path's only collective (metric record)
-    dt_max = float(tmax.item())
+        dist.all_reduce(tblk, op=dist.ReduceOp.MAX)
+        rec = torch.tensor([rank, seed, tr.total_it, *last.tolist()], dtype=torch.float64, device=cdev)
+        gathered = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(gathered, rec)  # RCCL: the path's only collective (metric record)
+        recs = [dict(zip(("rank", "seed", "total_it", "value_loss", "q_loss", "actor_loss"), g.tolist()))
+                for g in gathered]
+    blk = np.sort(tblk.cpu().numpy())
+    dt_med = float(np.median(blk))
+    dev_ms_med = float(np.median(block_dev_ms))
 
     if rank == 0:
         cfg = tr._cfg(BATCH)
         bytes_step, flops_step = C.c_double(), C.c_double()
         _lib.check(_lib.load().iqlhip_step_cost(C.byref(cfg), C.byref(bytes_step), C.byref(flops_step)))
-        steps_per_s = world * args.steps / dt_max
-        step_us_dev = dev_ms * 1e3 / args.steps
-        achieved = bytes_step.value / (step_us_dev * 1e-6) / 1e9  # GB/s, device time of this rank
+        steps_per_s = world * K / dt_med
+        step_us_dev = dev_ms_med * 1e3 / K
         # per-kernel breakdown (diagnostic pass with HIP events around every launch)
         lib = _lib.load()
         _lib.check(lib.iqlhip_trainer_set_timing(tr._handle, 1))
@@ -192,29 +288,43 @@ def main():
         upd_bytes = bytes_step.value - gather_bytes
         # HIP events on the launch stream give each kernel's share of a step; the shares are
         # scaled so that the three launches tile the measured device time per step, which is how
-        # rocprofv3 --kernel-trace attributes the timeline (dispatch to completion, back to back):
-        # profiles/r01_e_kernel_stats.csv is the cross-check
+        # rocprofv3 --kernel-trace attributes the timeline (dispatch to completion, back to back)
         ev_us = [avg[k] * 1e3 for k in range(3)]
         scale = step_us_dev / sum(ev_us) if sum(ev_us) > 0 else 1.0
         upd_us = ev_us[2] * scale
         achieved = upd_bytes / (upd_us * 1e-6) / 1e9  # GB/s of k_update
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_e_traffic.json")
-        if os.path.exists(tpath):  # PMC pass (separate rocprofv3 --pmc runs), bytes per launch of k_update
+        traffic, traffic_src = None, None
+        tname = os.environ.get("IQL_TRAFFIC_PROFILE", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath):  # PMC passes (separate rocprofv3 --pmc runs, tools/profile.sh)
             with open(tpath) as f:
-                traffic = json.load(f).get("k_update_bytes_per_launch")
+                tj = json.load(f)
+            traffic = tj.get("k_update_bytes_per_launch")
+            traffic_src = {"file": f"profiles/{tname}", "build": tj.get("build"),
+                           "note": "PMC (2*FETCH_SIZE + WRITE_SIZE) of an earlier rocprofv3 run of this "
+                                   "command; not collected in this timed run",
+                           "matches_this_build": tj.get("build") == _lib.build_tag()}
         out = {
             "metric": "iql_grad_steps_per_sec", "value": steps_per_s, "unit": "steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_max * 1e3 / args.steps, "higher_is_better": True,
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": dt_med * 1e3 / K, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "IQL antmaze-medium-diverse-v2 shapes (S=29 A=8 H=256), "
                                    "1M-transition device replay, batch 256, one seed per GPU",
-                       "batch": BATCH, "buffer_rows": N_ROWS, "graph_unroll": args.unroll},
+                       "batch": BATCH, "buffer_rows": N_ROWS, "graph_unroll": unroll,
+                       "graph_launches_per_block": K // unroll, "eager_steps_per_block": K % unroll},
+            "timing": {"reps": reps, "timed_steps_total": reps * K,
+                       "block_ms": {"median": dt_med * 1e3, "min": float(blk[0]) * 1e3,
+                                    "max": float(blk[-1]) * 1e3},
+                       "ms_per_step_device": dev_ms_med / K,
+                       "note": "each block = K steps between barrier+synchronize pairs; median block, "
+                               "max over ranks; *_device = HIP events on the launch stream"},
+            "build": _lib.build_tag(),
             "roofline": {
                 "kernel": "k_update", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": upd_bytes, "launch_us": upd_us,
                 "launch_us_events_only": ev_us[2], "launches_timed": int(nl.value),
                 "step": {"bytes_per_step": bytes_step.value, "device_us_per_step": step_us_dev,
@@ -229,40 +339,67 @@ def main():
                          else MFMA_F32_PEAK_TFLOPS},
             },
         }
-        if world == 1 and args.agents_per_gpu > 1:
-            # independent seeds on independent streams; same dataset (a sweep varies the seed only)
-            A_ = args.agents_per_gpu
-            trs = [tr] + [build_trainer(ia, torch, device, seed + 100 + i, args.precision) for i in range(1, A_)]
-            group = ia.SeedGroup(trs)
-            group.train_steps(buf, 2_000, BATCH, graph_unroll=args.unroll)
+        if recs is not None:
+            out["ranks"] = recs
+        if world == 1 and K < 5_000:
+            # the same path sustained over a long region, for comparison with the K-step blocks
+            n_long = 20_000 // unroll * unroll
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            n_multi = 20_000
-            group.train_steps(buf, n_multi, BATCH, graph_unroll=args.unroll)
+            run(n_long)
             torch.cuda.synchronize()
-            dt_m = time.perf_counter() - t1
-            out["agents_per_gpu"] = {"agents": A_, "value": A_ * n_multi / dt_m, "unit": "steps/s",
-                                     "steps_per_agent": n_multi,
-                                     "note": "aggregate of independent seeds sharing one GPU; not `value`"}
+            out["sustained"] = {"steps": n_long, "value": n_long / (time.perf_counter() - t1), "unit": "steps/s",
+                                "note": "one timed region of this many steps, same graphs; not `value`"}
+        if world == 1 and args.agents_per_gpu > 1:
+            out["agents_per_gpu"] = agents_leg(ia, torch, tr, buf, device, seed, args, unroll, bytes_step.value)
         if world == 1 and args.ensemble_q >= 2:
             E_ = args.ensemble_q
             tre = build_trainer(ia, torch, device, seed + 50, args.precision, n_critics=E_)
-            tre.train_steps(buf, 1_000, 1024, return_losses=False, graph_unroll=args.unroll)
+            tre.train_steps(buf, 1_000, 1024, return_losses=False, graph_unroll=50)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             n_e = 5_000
-            tre.train_steps(buf, n_e, 1024, return_losses=False, graph_unroll=args.unroll)
+            tre.train_steps(buf, n_e, 1024, return_losses=False, graph_unroll=50)
             torch.cuda.synchronize()
             dt_e = time.perf_counter() - t1
             out["ensemble_q"] = {"n_critics": E_, "batch": 1024, "value": n_e / dt_e, "unit": "steps/s",
                                  "transitions_per_s": 1024 * n_e / dt_e,
                                  "note": "BASELINE configs[4] (E-way critic ensemble, batch 1024); not `value`"}
+            del tre
+        if world == 1 and not args.no_relabel:
+            try:
+                from tools import bench_relabel
+                out["relabel"] = bench_relabel.leg(device)
+            except Exception as e:  # the leg must never take the headline down with it
+                out["relabel"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def agents_leg(ia, torch, tr, buf, device, seed, args, unroll, bytes_step):
+    """Independent seeds sharing one GPU (same dataset: a sweep varies the seed only)."""
+    A_ = args.agents_per_gpu
+    trs = [tr] + [build_trainer(ia, torch, device, seed + 100 + i, args.precision) for i in range(1, A_)]
+    group = ia.SeedGroup(trs)
+    u = 50
+    group.train_steps(buf, 2_000, BATCH, graph_unroll=u)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    n_multi = 20_000
+    group.train_steps(buf, n_multi, BATCH, graph_unroll=u)
+    torch.cuda.synchronize()
+    dt_m = time.perf_counter() - t1
+    v = A_ * n_multi / dt_m
+    return {"agents": A_, "value": v, "unit": "steps/s", "steps_per_agent": n_multi,
+            "mode": getattr(group, "mode", "streams"),
+            "roofline": {"bound": "hbm", "achieved": v * bytes_step / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": v * bytes_step / 1e9 / HBM_PEAK_GBS,
+                         "note": "whole step: aggregate steps/s x algorithmic bytes per step"},
+            "note": "aggregate of independent seeds sharing one GPU; not `value`"}
 
 
 if __name__ == "__main__":

@@ -37,6 +37,25 @@ typedef enum {
 const char *iqlhip_last_error(void);
 /* ABI version of this header; bumped on any incompatible change. */
 int iqlhip_abi_version(void);
+/* 16 hex digits: sha256 prefix of the sources (csrc/ + this header + compiler flags) the
+ * library was built from, stamped by iqlpref_amd/build.py.  The Python binding refuses a
+ * library whose tag differs from the sources beside it.                                  */
+const char *iqlhip_build_tag(void);
+
+/* ------------------------------------------------------------------------ */
+/* Shape envelope (everything outside returns IQLHIP_ERR_UNSUPPORTED with a   */
+/* message; every YAML under the reference's configs/offline/iql/ fits):      */
+/*   trainer   n_hidden = 2 (three Linear layers per net), ReLU hidden         */
+/*             activations, hidden_dim in {64, 128, 256}, batch_size a         */
+/*             multiple of 16, state_dim + action_dim <= 128, action_dim <= 32,*/
+/*             2..8 critics, plain Adam (no weight decay / amsgrad), one       */
+/*             (beta1, beta2, eps) for the three optimisers;                   */
+/*   MLP fwd   1..8 layers, every width in [1, 256];                           */
+/*   CVaR      1 <= n_tail <= S <= 2400;                                       */
+/*   PT        embd_dim 64, ONE GPT-2 block, num_heads a power of two <= 16,   */
+/*             inter_dim a multiple of 256 up to 1024, state_dim + action_dim  */
+/*             <= 192, query_length such that the window fits the 160 KiB LDS. */
+/* ------------------------------------------------------------------------ */
 
 /* ------------------------------------------------------------------------ */
 /* Replay buffer  (ref:164-226 ReplayBuffer)                                 */

@@ -15,7 +15,7 @@ PREC_BF16 = 1
 MAX_CRITICS = 8
 N_TENSORS = 6 * (MAX_CRITICS + 2) + 1
 MLP_MAX_LAYERS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ERR_INVALID = -1
 ERR_HIP = -2
@@ -71,6 +71,7 @@ P = C.c_void_p
 SYMBOLS = {
     "iqlhip_last_error": (C.c_char_p, []),
     "iqlhip_abi_version": (C.c_int, []),
+    "iqlhip_build_tag": (C.c_char_p, []),
     "iqlhip_replay_row_stride": (C.c_int32, [C.c_int32, C.c_int32]),
     "iqlhip_replay_pack": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
                                      P, P, P, P, P, P]),
@@ -116,8 +117,20 @@ def load():
         fn.argtypes = args
     if lib.iqlhip_abi_version() != ABI_VERSION:
         raise ImportError("libiqlhip.so ABI version mismatch; rebuild it")
+    if not os.environ.get("IQLHIP_LIB"):  # an explicitly named other build is taken as it is
+        from . import build as _build
+        want, have = _build.source_tag(), lib.iqlhip_build_tag().decode()
+        if want != have:
+            raise ImportError(
+                f"{LIB_PATH} was built from other sources (library tag {have}, sources {want}): "
+                "rebuild it with `python -m iqlpref_amd.build`")
     _lib = lib
     return lib
+
+
+def build_tag():
+    """Source hash the loaded library was built from (iqlpref_amd/build.py)."""
+    return load().iqlhip_build_tag().decode()
 
 
 def check(rc):

@@ -64,7 +64,14 @@ static int fail(int code, const char *fmt, ...) {
   } while (0)
 
 extern "C" const char *iqlhip_last_error(void) { return g_err; }
-extern "C" int iqlhip_abi_version(void) { return 2; }
+extern "C" int iqlhip_abi_version(void) { return 3; }
+// sha256 prefix of csrc/* + include/iqlhip.h, stamped by iqlpref_amd/build.py: the Python side
+// refuses a library whose tag does not match the sources it sits beside
+#ifndef IQLHIP_BUILD_TAG
+#define IQLHIP_BUILD_TAG "untagged"
+#endif
+static const char g_build_tag[] = "IQLHIP_BUILD_TAG=" IQLHIP_BUILD_TAG;  // marker: build.py reads it from the file
+extern "C" const char *iqlhip_build_tag(void) { return g_build_tag + sizeof("IQLHIP_BUILD_TAG=") - 1; }
 
 // ------------------------------------------------------------------ replay --
 extern "C" int32_t iqlhip_replay_row_stride(int32_t S, int32_t A) { return round_up(2 * S + A + 2, 4); }
@@ -107,6 +114,15 @@ struct iqlhip_trainer {
 
   float *batch_rows = nullptr;  // [B][stride] staging for iqlhip_train_batch
   int64_t call_id = 0;          // tags the batches prefetched during one run_steps call
+  // DevArgs travel through a small ring of pinned host slots (a pageable source makes
+  // hipMemcpyAsync host-blocking, which serialised the streams of a SeedGroup); a slot is
+  // reused only after the copy that read it has completed (its event)
+  static constexpr int ARG_RING = 8;
+  DevArgs *harg[ARG_RING] = {};
+  hipEvent_t harg_ev[ARG_RING] = {};
+  bool harg_used[ARG_RING] = {};
+  int harg_head = 0;
+
   int64_t total_it = 0;
   double lr_q, lr_v, lr_a_base;
   // hipGraph of `graph_unroll` steps
@@ -459,6 +475,10 @@ extern "C" int iqlhip_trainer_destroy(iqlhip_trainer *t) {
   if (!t) return 0;
   if (t->gexec) (void)hipGraphExecDestroy(t->gexec);
   if (t->cap_stream) (void)hipStreamDestroy(t->cap_stream);
+  for (int k = 0; k < iqlhip_trainer::ARG_RING; ++k) {
+    if (t->harg_ev[k]) (void)hipEventDestroy(t->harg_ev[k]);
+    if (t->harg[k]) (void)hipHostFree(t->harg[k]);
+  }
 
   for (auto &e : t->ev)
     if (e) (void)hipEventDestroy(e);
@@ -475,10 +495,14 @@ extern "C" int iqlhip_trainer_sync_weights(iqlhip_trainer *t, void *stream) {
 
 extern "C" int iqlhip_trainer_set_step(iqlhip_trainer *t, int64_t total_it) {
   if (!t || total_it < 0) return fail(IQLHIP_ERR_INVALID, "bad argument");
+  // rare (init, load_state_dict): drain every stream first, so that no step in flight on a
+  // non-blocking stream can race the counter write below
+  HIP_TRY(hipDeviceSynchronize());
   t->total_it = total_it;
   DevCtr c;
   memset(&c, 0, sizeof(c));
   c.ctr[0] = total_it, c.ctr[1] = total_it;
+  c.staged_step = -1;
   HIP_TRY(hipMemcpy(t->dctr, &c, sizeof(c), hipMemcpyHostToDevice));
   return 0;
 }
@@ -530,12 +554,29 @@ static int enqueue_step(iqlhip_trainer *t, hipStream_t st) {
   return 0;
 }
 
-static int run_steps(iqlhip_trainer *t, const DevArgs &args_in, int64_t n_steps, int graph_unroll,
-                     hipStream_t st) {
+static hipError_t push_args(iqlhip_trainer *t, const DevArgs &args_in, int64_t n_steps, hipStream_t st) {
   DevArgs args = args_in;
   args.n_steps = n_steps;
   args.call_id = ++t->call_id;
-  HIP_TRY(hipMemcpyAsync(t->dargs, &args, sizeof(DevArgs), hipMemcpyHostToDevice, st));
+  const int k = t->harg_head;
+  t->harg_head = (k + 1) % iqlhip_trainer::ARG_RING;
+  hipError_t e;
+  if (!t->harg[k]) {
+    if ((e = hipHostMalloc((void **)&t->harg[k], sizeof(DevArgs), hipHostMallocDefault)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&t->harg_ev[k], hipEventDisableTiming)) != hipSuccess) return e;
+  }
+  if (t->harg_used[k] && (e = hipEventSynchronize(t->harg_ev[k])) != hipSuccess) return e;
+  *t->harg[k] = args;
+  if ((e = hipMemcpyAsync(t->dargs, t->harg[k], sizeof(DevArgs), hipMemcpyHostToDevice, st)) != hipSuccess)
+    return e;
+  if ((e = hipEventRecord(t->harg_ev[k], st)) != hipSuccess) return e;
+  t->harg_used[k] = true;
+  return hipSuccess;
+}
+
+static int run_steps(iqlhip_trainer *t, const DevArgs &args_in, int64_t n_steps, int graph_unroll,
+                     hipStream_t st) {
+  HIP_TRY(push_args(t, args_in, n_steps, st));
   int64_t done = 0;
   if (t->timing) {
     // one event pair per kernel: serialises the stream a little; diagnostic mode only

@@ -15,16 +15,41 @@ FIELDS = ("seed", "total_it", "value_loss", "q_loss", "actor_loss", "mean_score"
           "avg_steps_to_goal", "steps_per_sec", "rank")
 
 
+def device_for_rank(local_rank: int, n_visible: int) -> str:
+    """The GPU a rank owns: ``cuda:<LOCAL_RANK>`` (one process per GPU, the reference's
+    ``CUDA_VISIBLE_DEVICES=$gpu wandb agent``, ensemble_sweeps/launch.sh:91).  More local ranks
+    than visible GPUs is an error, never a silent share of GPU 0."""
+    if local_rank < 0 or local_rank >= max(n_visible, 1):
+        raise RuntimeError(f"LOCAL_RANK {local_rank} but only {n_visible} GPU(s) visible: "
+                           "launch one rank per GPU")
+    return f"cuda:{local_rank}"
+
+
+def local_device() -> Optional[str]:
+    """Under a torchrun-style launch (WORLD_SIZE > 1): bind this process to its GPU before
+    anything else touches a device and return the indexed device string every later object
+    (process group, replay buffer, trainer, collective payloads) must use.  None when the
+    process is not part of a multi-rank job or has no GPU (gloo CPU tests)."""
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 or not torch.cuda.is_available():
+        return None
+    dev = device_for_rank(int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.device_count())
+    torch.cuda.set_device(torch.device(dev))
+    return dev
+
+
 def init_from_env(backend: Optional[str] = None, device: Optional[str] = None) -> int:
     """torchrun-style rendezvous (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
-    Returns the rank; a no-op (rank 0) when WORLD_SIZE is 1 or unset."""
+    Returns the rank; a no-op (rank 0) when WORLD_SIZE is 1 or unset.  ``device`` must be an
+    indexed device (``cuda:3``) for the RCCL backend; ``local_device()`` supplies it."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1 or dist.is_initialized():
         return dist.get_rank() if dist.is_initialized() else 0
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     kw = {}
-    if backend == "nccl" and device is not None:
+    if backend == "nccl":
+        if device is None or torch.device(device).index is None:
+            device = local_device()
         kw["device_id"] = torch.device(device)
     dist.init_process_group(backend, **kw)
     return dist.get_rank()

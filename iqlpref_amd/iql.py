@@ -697,8 +697,10 @@ class ImplicitQLearning:
         }
 
     def load_state_dict(self, state_dict: Dict[str, Any]):
-        strip = lambda sd: {(k[len("_orig_mod."):] if k.startswith("_orig_mod.") else k): v
-                            for k, v in sd.items()}
+        # nothing of this trainer may still be in flight (SeedGroup streams are non-blocking)
+        torch.cuda.synchronize(self._dev)
+        # checkpoints written after torch.compile wrapped the nets (ref:1523-1528) carry this prefix
+        strip = lambda sd: {k.removeprefix("_orig_mod."): v for k, v in sd.items()}
         self.qf.load_state_dict(strip(state_dict["qf"]))  # copies into the arena views
         self.q_optimizer.load_state_dict(state_dict["q_optimizer"])
         self.vf.load_state_dict(strip(state_dict["vf"]))
@@ -708,7 +710,10 @@ class ImplicitQLearning:
         self.actor_lr_schedule.load_state_dict(state_dict["actor_lr_schedule"])
         self.total_it = state_dict["total_it"]
         # optimizer.load_state_dict made fresh moment tensors: move them into the arenas
+        # (a checkpoint taken before the first step has no moments: they are zero, not stale)
         with torch.no_grad():
+            self._exp_avg.zero_()
+            self._exp_avg_sq.zero_()
             for p, o in self._views:
                 for opt in (self.q_optimizer, self.v_optimizer, self.actor_optimizer):
                     st = opt.state.get(p)

@@ -118,6 +118,11 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
     ``raw_dataset``: an env.get_dataset()-style dict handed to the relabel functions;
     ``evaluate(actor, step) -> (scores, steps_to_goal)`` replaces eval_actor when gym is
     not installed (None: evaluation is skipped)."""
+    # one process per GPU: under torchrun this rank owns cuda:<LOCAL_RANK>, and everything
+    # below (process group, buffer, trainer, metric all-gather) lives there
+    bound = D.local_device()
+    if bound is not None:
+        config.device = bound
     rank = D.init_from_env(device=config.device)
     if env is None and (state_dim is None or action_dim is None):
         import gym
