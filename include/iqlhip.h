@@ -170,6 +170,26 @@ int iqlhip_train_steps(iqlhip_trainer *t, const iqlhip_replay_view *view, int64_
                        const int64_t *idx, const uint8_t *dropout_keep, float *losses_out,
                        int32_t graph_unroll, void *stream);
 
+/* ------------------------------------------------------------------------ */
+/* Seed groups: K independent trainers of ONE shape (dims, batch, precision,   */
+/* critics, policy kind, dropout on/off) stepped by one launch sequence -- the */
+/* three kernels of a step run with gridDim.y = K.  The seeds share nothing;   */
+/* each one's arithmetic is bit-identical to stepping it alone.  This is the   */
+/* path's sharding unit (one (seed, dataset) run, ensemble_sweeps/launch.sh:   */
+/* 12 AGENTS_PER_GPU, :84-94) used inside one GPU.                              */
+/* While a trainer is a member, its own iqlhip_train_* calls keep working;     */
+/* destroy the group before its members.  views[k], idx[k], dropout_keep[k],   */
+/* losses_out[k] belong to member k (idx / dropout_keep / losses_out may be    */
+/* NULL as a whole or per member; meaning as in iqlhip_train_steps).           */
+/* ------------------------------------------------------------------------ */
+#define IQLHIP_MAX_GROUP 16
+typedef struct iqlhip_group iqlhip_group;
+int iqlhip_group_create(iqlhip_group **out, iqlhip_trainer *const *trainers, int32_t n);
+int iqlhip_group_destroy(iqlhip_group *g);
+int iqlhip_group_train_steps(iqlhip_group *g, const iqlhip_replay_view *views, int64_t n_steps,
+                             const int64_t *const *idx, const uint8_t *const *dropout_keep,
+                             float *const *losses_out, int32_t graph_unroll, void *stream);
+
 /* ref:639-662 train(batch) on an explicit batch of dense device tensors
  * (shapes as iqlhip_replay_sample produces them).                           */
 int iqlhip_train_batch(iqlhip_trainer *t, const float *s, const float *a, const float *r,

@@ -15,6 +15,7 @@ PREC_BF16 = 1
 MAX_CRITICS = 8
 N_TENSORS = 6 * (MAX_CRITICS + 2) + 1
 MLP_MAX_LAYERS = 8
+MAX_GROUP = 16
 ABI_VERSION = 3
 
 ERR_INVALID = -1
@@ -86,6 +87,10 @@ SYMBOLS = {
     "iqlhip_trainer_get_step": (C.c_int, [P, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "iqlhip_trainer_set_lr": (C.c_int, [P, C.c_double, C.c_double, C.c_double]),
     "iqlhip_train_steps": (C.c_int, [P, C.POINTER(ReplayView), C.c_int64, P, P, P, C.c_int32, P]),
+    "iqlhip_group_create": (C.c_int, [C.POINTER(P), C.POINTER(P), C.c_int32]),
+    "iqlhip_group_destroy": (C.c_int, [P]),
+    "iqlhip_group_train_steps": (C.c_int, [P, C.POINTER(ReplayView), C.c_int64, C.POINTER(P), C.POINTER(P),
+                                           C.POINTER(P), C.c_int32, P]),
     "iqlhip_train_batch": (C.c_int, [P, P, P, P, P, P, P, P, P]),
     "iqlhip_forward": (C.c_int, [P, C.c_int32, P, P, C.c_int64, P, P]),
     "iqlhip_mlp_forward": (C.c_int, [C.POINTER(MlpDesc), P, C.c_int64, C.c_int32, P, C.c_int32, P]),

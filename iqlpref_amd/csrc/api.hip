@@ -18,12 +18,12 @@ namespace iqlhip {
 size_t fwd_smem_bytes(bool bf16, int H, int k1max);
 size_t bwd_smem_bytes(bool bf16, int H);
 hipError_t launch_forward(bool, const TrainerDesc &, const TrainerDesc *, const DevArgs *, const DevCtr *,
-                          hipStream_t);
+                          int n_seeds, hipStream_t);
 hipError_t launch_backward(bool, const TrainerDesc &, const TrainerDesc *, const DevArgs *, DevCtr *,
-                           hipStream_t);
+                           int n_seeds, hipStream_t);
 int strip_rows();
 hipError_t launch_update(bool, const TrainerDesc *, const DevArgs *, DevCtr *, const UpdItem *, int,
-                         hipStream_t);
+                         int n_seeds, hipStream_t);
 hipError_t launch_sync_weights(bool, const TrainerDesc *, hipStream_t);
 
 hipError_t launch_infer(bool, const TrainerDesc &, const TrainerDesc *, const FwdNet &, const float *,
@@ -111,6 +111,13 @@ struct iqlhip_trainer {
   DevCtr *dctr = nullptr;
   UpdItem *ditems = nullptr;
   int n_items = 0;
+  // the slots of this trainer's own workspace; ddesc / dargs / dctr / ditems point into a
+  // group's contiguous arrays while the trainer is a member of one (iqlhip_group_create)
+  TrainerDesc *own_ddesc = nullptr;
+  DevArgs *own_dargs = nullptr;
+  DevCtr *own_dctr = nullptr;
+  UpdItem *own_ditems = nullptr;
+  struct iqlhip_group *group = nullptr;
 
   float *batch_rows = nullptr;  // [B][stride] staging for iqlhip_train_batch
   int64_t call_id = 0;          // tags the batches prefetched during one run_steps call
@@ -408,10 +415,10 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   D.stage_rows = carve<float>(p, (size_t)B * stride);
   D.stage_stride = stride;
   if (n_pad == 0 || getenv("IQLHIP_NO_PREFETCH")) D.stage_rows = nullptr;
-  t->dargs = carve<DevArgs>(p, 1);
-  t->dctr = carve<DevCtr>(p, 1);
-  t->ddesc = carve<TrainerDesc>(p, 1);
-  t->ditems = carve<UpdItem>(p, items.size());
+  t->own_dargs = t->dargs = carve<DevArgs>(p, 1);
+  t->own_dctr = t->dctr = carve<DevCtr>(p, 1);
+  t->own_ddesc = t->ddesc = carve<TrainerDesc>(p, 1);
+  t->own_ditems = t->ditems = carve<UpdItem>(p, items.size());
 
   for (auto &it : items) {
     if (it.net < 0) continue;
@@ -473,6 +480,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
 
 extern "C" int iqlhip_trainer_destroy(iqlhip_trainer *t) {
   if (!t) return 0;
+  if (t->group) return fail(IQLHIP_ERR_INVALID, "trainer is a member of a group: destroy the group first");
   if (t->gexec) (void)hipGraphExecDestroy(t->gexec);
   if (t->cap_stream) (void)hipStreamDestroy(t->cap_stream);
   for (int k = 0; k < iqlhip_trainer::ARG_RING; ++k) {
@@ -548,9 +556,9 @@ extern "C" int iqlhip_trainer_get_timing(iqlhip_trainer *t, double avg_ms[3], in
 }
 
 static int enqueue_step(iqlhip_trainer *t, hipStream_t st) {
-  HIP_TRY(launch_forward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, st));
-  HIP_TRY(launch_backward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, st));
-  HIP_TRY(launch_update(t->bf16, t->ddesc, t->dargs, t->dctr, t->ditems, t->n_items, st));
+  HIP_TRY(launch_forward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, 1, st));
+  HIP_TRY(launch_backward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, 1, st));
+  HIP_TRY(launch_update(t->bf16, t->ddesc, t->dargs, t->dctr, t->ditems, t->n_items, 1, st));
   return 0;
 }
 
@@ -582,11 +590,11 @@ static int run_steps(iqlhip_trainer *t, const DevArgs &args_in, int64_t n_steps,
     // one event pair per kernel: serialises the stream a little; diagnostic mode only
     for (; done < n_steps; ++done) {
       HIP_TRY(hipEventRecord(t->ev[0], st));
-      HIP_TRY(launch_forward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, st));
+      HIP_TRY(launch_forward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, 1, st));
       HIP_TRY(hipEventRecord(t->ev[1], st));
-      HIP_TRY(launch_backward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, st));
+      HIP_TRY(launch_backward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, 1, st));
       HIP_TRY(hipEventRecord(t->ev[2], st));
-      HIP_TRY(launch_update(t->bf16, t->ddesc, t->dargs, t->dctr, t->ditems, t->n_items, st));
+      HIP_TRY(launch_update(t->bf16, t->ddesc, t->dargs, t->dctr, t->ditems, t->n_items, 1, st));
       HIP_TRY(hipEventRecord(t->ev[3], st));
       HIP_TRY(hipEventRecord(t->ev[4], st));  // empty interval: what a record pair costs by itself
       HIP_TRY(hipEventSynchronize(t->ev[4]));
@@ -669,6 +677,200 @@ extern "C" int iqlhip_train_batch(iqlhip_trainer *t, const float *s, const float
   t->total_it += 1;
   return 0;
 }
+
+// ------------------------------------------------------------------ groups --
+// K independent trainers (seeds) of one shape stepped by ONE launch sequence: every kernel
+// runs with gridDim.y = K and work-group (x, k) does for seed k exactly what work-group x of
+// a solo launch does -- the arithmetic of every seed is bit-identical to running it alone.
+// One seed at batch 256 is a latency chain on a fraction of the chip; K seeds per launch
+// fill it and pay the kernel boundaries once per K seed-steps (the reference runs several
+// agents per GPU for the same reason, ensemble_sweeps/launch.sh:12 AGENTS_PER_GPU).
+struct iqlhip_group {
+  int K = 0;
+  iqlhip_trainer *tr[IQLHIP_MAX_GROUP] = {};
+  void *mem = nullptr;  // [K] TrainerDesc | [K] DevArgs | [K] DevCtr | [K][n_items] UpdItem
+  TrainerDesc *gdesc = nullptr;
+  DevArgs *gargs = nullptr;
+  DevCtr *gctr = nullptr;
+  UpdItem *gitems = nullptr;
+  static constexpr int ARG_RING = 8;
+  DevArgs *harg[ARG_RING] = {};  // pinned, [K] each
+  hipEvent_t harg_ev[ARG_RING] = {};
+  bool harg_used[ARG_RING] = {};
+  int harg_head = 0;
+  hipGraphExec_t gexec = nullptr;
+  int graph_unroll = 0;
+  hipStream_t cap_stream = nullptr;
+};
+
+static bool same_shape(const iqlhip_trainer_config &a, const iqlhip_trainer_config &b) {
+  return a.state_dim == b.state_dim && a.action_dim == b.action_dim && a.hidden_dim == b.hidden_dim &&
+         a.batch_size == b.batch_size && a.deterministic == b.deterministic && a.precision == b.precision &&
+         n_critics(a) == n_critics(b) && (a.dropout_p > 0.f) == (b.dropout_p > 0.f);
+}
+
+extern "C" int iqlhip_group_create(iqlhip_group **out, iqlhip_trainer *const *trainers, int32_t n) {
+  if (!out || !trainers) return fail(IQLHIP_ERR_INVALID, "null argument");
+  if (n < 1 || n > IQLHIP_MAX_GROUP) return fail(IQLHIP_ERR_INVALID, "group size %d: 1..%d", n, IQLHIP_MAX_GROUP);
+  for (int k = 0; k < n; ++k) {
+    if (!trainers[k]) return fail(IQLHIP_ERR_INVALID, "null trainer");
+    if (trainers[k]->group) return fail(IQLHIP_ERR_INVALID, "trainer %d already belongs to a group", k);
+    for (int j = 0; j < k; ++j)
+      if (trainers[j] == trainers[k]) return fail(IQLHIP_ERR_INVALID, "trainer %d listed twice", k);
+    if (!same_shape(trainers[0]->cfg, trainers[k]->cfg) || trainers[k]->n_items != trainers[0]->n_items)
+      return fail(IQLHIP_ERR_INVALID, "trainer %d differs in shape from trainer 0 (dims, batch, precision, "
+                  "critics, policy kind and dropout on/off must match)", k);
+  }
+  iqlhip_group *g = new (std::nothrow) iqlhip_group();
+  if (!g) return fail(IQLHIP_ERR_NOMEM, "host allocation failed");
+  g->K = n;
+  const int ni = trainers[0]->n_items;
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t b_desc = up(sizeof(TrainerDesc) * n), b_args = up(sizeof(DevArgs) * n),
+               b_ctr = up(sizeof(DevCtr) * n), b_items = up(sizeof(UpdItem) * (size_t)ni * n);
+  HIP_TRY(hipDeviceSynchronize());  // members may have steps in flight on other streams
+  if (hipMalloc(&g->mem, b_desc + b_args + b_ctr + b_items) != hipSuccess) {
+    delete g;
+    return fail(IQLHIP_ERR_NOMEM, "hipMalloc of the group descriptors failed");
+  }
+  char *p = reinterpret_cast<char *>(g->mem);
+  g->gdesc = reinterpret_cast<TrainerDesc *>(p), p += b_desc;
+  g->gargs = reinterpret_cast<DevArgs *>(p), p += b_args;
+  g->gctr = reinterpret_cast<DevCtr *>(p), p += b_ctr;
+  g->gitems = reinterpret_cast<UpdItem *>(p);
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < n && e == hipSuccess; ++k) {
+    iqlhip_trainer *t = trainers[k];
+    e = hipMemcpy(g->gdesc + k, t->ddesc, sizeof(TrainerDesc), hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->gargs + k, t->dargs, sizeof(DevArgs), hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->gctr + k, t->dctr, sizeof(DevCtr), hipMemcpyDeviceToDevice);
+    if (e == hipSuccess)
+      e = hipMemcpy(g->gitems + (size_t)k * ni, t->ditems, sizeof(UpdItem) * ni, hipMemcpyDeviceToDevice);
+  }
+  if (e != hipSuccess) {
+    (void)hipFree(g->mem);
+    delete g;
+    return fail(IQLHIP_ERR_HIP, "copying the member descriptors failed: %s", hipGetErrorString(e));
+  }
+  for (int k = 0; k < n; ++k) {
+    iqlhip_trainer *t = trainers[k];
+    g->tr[k] = t;
+    t->group = g;
+    t->ddesc = g->gdesc + k, t->dargs = g->gargs + k, t->dctr = g->gctr + k, t->ditems = g->gitems + (size_t)k * ni;
+    if (t->gexec) {  // the member's own graph holds the old descriptor addresses
+      (void)hipGraphExecDestroy(t->gexec);
+      t->gexec = nullptr;
+    }
+  }
+  *out = g;
+  return 0;
+}
+
+// Members go back to their own workspace slots (with the group's current counters) and stay
+// usable on their own.
+extern "C" int iqlhip_group_destroy(iqlhip_group *g) {
+  if (!g) return 0;
+  (void)hipDeviceSynchronize();
+  for (int k = 0; k < g->K; ++k) {
+    iqlhip_trainer *t = g->tr[k];
+    (void)hipMemcpy(t->own_dctr, t->dctr, sizeof(DevCtr), hipMemcpyDeviceToDevice);
+    t->ddesc = t->own_ddesc, t->dargs = t->own_dargs, t->dctr = t->own_dctr, t->ditems = t->own_ditems;
+    t->group = nullptr;
+    if (t->gexec) {
+      (void)hipGraphExecDestroy(t->gexec);
+      t->gexec = nullptr;
+    }
+  }
+  if (g->gexec) (void)hipGraphExecDestroy(g->gexec);
+  if (g->cap_stream) (void)hipStreamDestroy(g->cap_stream);
+  for (int k = 0; k < iqlhip_group::ARG_RING; ++k) {
+    if (g->harg_ev[k]) (void)hipEventDestroy(g->harg_ev[k]);
+    if (g->harg[k]) (void)hipHostFree(g->harg[k]);
+  }
+  if (g->mem) (void)hipFree(g->mem);
+  delete g;
+  return 0;
+}
+
+static int group_enqueue_step(iqlhip_group *g, hipStream_t st) {
+  iqlhip_trainer *t0 = g->tr[0];
+  HIP_TRY(launch_forward(t0->bf16, t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
+  HIP_TRY(launch_backward(t0->bf16, t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
+  HIP_TRY(launch_update(t0->bf16, g->gdesc, g->gargs, g->gctr, g->gitems, t0->n_items, g->K, st));
+  return 0;
+}
+
+extern "C" int iqlhip_group_train_steps(iqlhip_group *g, const iqlhip_replay_view *views, int64_t n_steps,
+                                        const int64_t *const *idx, const uint8_t *const *dropout_keep,
+                                        float *const *losses_out, int32_t graph_unroll, void *stream) {
+  if (!g || !views) return fail(IQLHIP_ERR_INVALID, "null argument");
+  if (n_steps < 0) return fail(IQLHIP_ERR_INVALID, "n_steps must be >= 0");
+  for (int k = 0; k < g->K; ++k) {
+    const iqlhip_replay_view &v = views[k];
+    const iqlhip_trainer_config &c = g->tr[k]->cfg;
+    if (!v.rows) return fail(IQLHIP_ERR_INVALID, "null replay view %d", k);
+    if (v.state_dim != c.state_dim || v.action_dim != c.action_dim)
+      return fail(IQLHIP_ERR_INVALID, "replay dims (%d,%d) do not match the trainer (%d,%d)", v.state_dim,
+                  v.action_dim, c.state_dim, c.action_dim);
+    if (v.n_rows <= 0) return fail(IQLHIP_ERR_INVALID, "cannot sample from an empty replay buffer");
+    if (v.row_stride < 2 * v.state_dim + v.action_dim + 2) return fail(IQLHIP_ERR_INVALID, "row_stride too small");
+  }
+  if (n_steps == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  // ---- K DevArgs through one pinned slot, one copy ----
+  const int slot = g->harg_head;
+  g->harg_head = (slot + 1) % iqlhip_group::ARG_RING;
+  if (!g->harg[slot]) {
+    HIP_TRY(hipHostMalloc((void **)&g->harg[slot], sizeof(DevArgs) * g->K, hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&g->harg_ev[slot], hipEventDisableTiming));
+  }
+  if (g->harg_used[slot]) HIP_TRY(hipEventSynchronize(g->harg_ev[slot]));
+  for (int k = 0; k < g->K; ++k) {
+    iqlhip_trainer *t = g->tr[k];
+    DevArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows = views[k].rows, a.n_rows = views[k].n_rows, a.row_stride = views[k].row_stride;
+    a.idx = idx ? idx[k] : nullptr;
+    a.idx_mode = a.idx ? 1 : 0;
+    a.drop_keep = dropout_keep ? dropout_keep[k] : nullptr;
+    a.losses_out = losses_out ? losses_out[k] : nullptr;
+    a.base_step = t->total_it;
+    a.lr_q = t->lr_q, a.lr_v = t->lr_v, a.lr_a_base = t->lr_a_base;
+    a.n_steps = n_steps;
+    a.call_id = ++t->call_id;
+    g->harg[slot][k] = a;
+  }
+  HIP_TRY(hipMemcpyAsync(g->gargs, g->harg[slot], sizeof(DevArgs) * g->K, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(g->harg_ev[slot], st));
+  g->harg_used[slot] = true;
+  // ---- the steps: hipGraphs of `graph_unroll` steps, the remainder eagerly ----
+  int64_t done = 0;
+  if (graph_unroll > 0 && n_steps >= graph_unroll) {
+    if (!g->gexec || g->graph_unroll != graph_unroll) {
+      if (g->gexec) {
+        (void)hipGraphExecDestroy(g->gexec);
+        g->gexec = nullptr;
+      }
+      hipGraph_t gr = nullptr;
+      if (!g->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&g->cap_stream, hipStreamNonBlocking));
+      HIP_TRY(hipStreamBeginCapture(g->cap_stream, hipStreamCaptureModeThreadLocal));
+      int rc = 0;
+      for (int u = 0; u < graph_unroll && !rc; ++u) rc = group_enqueue_step(g, g->cap_stream);
+      hipError_t ce = hipStreamEndCapture(g->cap_stream, &gr);
+      if (rc) return rc;
+      HIP_TRY(ce);
+      HIP_TRY(hipGraphInstantiate(&g->gexec, gr, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(gr);
+      g->graph_unroll = graph_unroll;
+    }
+    for (; done + graph_unroll <= n_steps; done += graph_unroll) HIP_TRY(hipGraphLaunch(g->gexec, st));
+  }
+  for (; done < n_steps; ++done)
+    if (int rc = group_enqueue_step(g, st)) return rc;
+  for (int k = 0; k < g->K; ++k) g->tr[k]->total_it += n_steps;
+  return 0;
+}
+
 
 extern "C" int iqlhip_forward(iqlhip_trainer *t, int32_t which, const float *s, const float *a, int64_t n,
                               float *out, void *stream) {

@@ -347,6 +347,9 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   // Job j (evaluation j < nfwd, or the spare job nfwd) lives on XCD j & 7, round j >> 3.
   // (nsl_ = B / 16 and nfwd_ arrive as preloaded kernel arguments: the job index, and with it
   // the address of this work-group's FwdNet, must not wait for a first descriptor load)
+  // blockIdx.y = seed of a group launch (iqlhip_group_*): the descriptors of the seeds of a
+  // group are contiguous arrays; a solo launch has gridDim.y = 1
+  Dp += blockIdx.y, Ap += blockIdx.y, Cp += blockIdx.y;
   const TrainerDesc &D = *Dp;
   const int idx_ = blockIdx.x >> 3;
   const int fnet = (idx_ / nsl_) * 8 + (blockIdx.x & 7), slab = idx_ % nsl_;
@@ -1285,14 +1288,18 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
                                                   const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
                                                   const int nslab, const int ntrain) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  backward_body<BF16, H>(Dp, Cp, (int)blockIdx.x, smem, nslab, ntrain);
+  backward_body<BF16, H>(Dp + blockIdx.y, Cp + blockIdx.y, (int)blockIdx.x, smem, nslab, ntrain);
 }
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ Dp,
                                                 const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
                                                 const UpdItem *__restrict__ items, int n_items) {
-  update_body<BF16>(Dp, Ap, Cp, items, n_items, (int)blockIdx.x);
+  // group launch: blockIdx.y = seed; grid.x is padded to a multiple of 8 (so that block -> XCD
+  // stays blockIdx.x & 7 for every seed), the blocks behind the misc block have nothing to do
+  if ((int)blockIdx.x > n_items) return;
+  update_body<BF16>(Dp + blockIdx.y, Ap + blockIdx.y, Cp + blockIdx.y, items + (size_t)blockIdx.y * n_items,
+                    n_items, (int)blockIdx.x);
 }
 
 // ========================================================================
@@ -1350,32 +1357,34 @@ size_t bwd_smem_bytes(bool bf16, int H) {
   } while (0)
 
 hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
-                          const DevCtr *c, hipStream_t st) {
+                          const DevCtr *c, int n_seeds, hipStream_t st) {
   const int grid = 8 * ((D.nfwd + 1 + 7) / 8) * (D.B / SLAB);  // nfwd evaluations + the spare job
   const size_t sm = fwd_smem_bytes(bf16, D.H, D.k1max);
 #define CALL(BF, HH) \
-  hipLaunchKernelGGL((k_forward<BF, HH>), dim3(grid), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.nfwd)
+  hipLaunchKernelGGL((k_forward<BF, HH>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.nfwd)
   DISPATCH_H(bf16, D.H, CALL);
 #undef CALL
   return hipGetLastError();
 }
 hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
-                           DevCtr *c, hipStream_t st) {
+                           DevCtr *c, int n_seeds, hipStream_t st) {
   const int grid = 8 * ((2 * D.ntrain + 7) / 8) * (D.H >= 128 ? D.B / SLAB : (D.B / SLAB + 1) / 2);
   const size_t sm = bwd_smem_bytes(bf16, D.H);
 #define CALL(BF, HH) \
-  hipLaunchKernelGGL((k_backward<BF, HH>), dim3(grid), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain)
+  hipLaunchKernelGGL((k_backward<BF, HH>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain)
   DISPATCH_H(bf16, D.H, CALL);
 #undef CALL
   return hipGetLastError();
 }
 int strip_rows() { return USR; }
 hipError_t launch_update(bool bf16, const TrainerDesc *dD, const DevArgs *a, DevCtr *c,
-                         const UpdItem *items, int n_items, hipStream_t st) {
+                         const UpdItem *items, int n_items, int n_seeds, hipStream_t st) {
+  // n_items tiles + the misc block; a group launch pads grid.x to a multiple of 8
+  const dim3 grid(n_seeds > 1 ? round_up(n_items + 1, 8) : n_items + 1, n_seeds);
   if (bf16)
-    hipLaunchKernelGGL(k_update<true>, dim3(n_items + 1), dim3(256), 0, st, dD, a, c, items, n_items);
+    hipLaunchKernelGGL(k_update<true>, grid, dim3(256), 0, st, dD, a, c, items, n_items);
   else
-    hipLaunchKernelGGL(k_update<false>, dim3(n_items + 1), dim3(256), 0, st, dD, a, c, items, n_items);
+    hipLaunchKernelGGL(k_update<false>, grid, dim3(256), 0, st, dD, a, c, items, n_items);
   return hipGetLastError();
 }
 hipError_t launch_infer(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const FwdNet &N,

@@ -476,6 +476,7 @@ class ImplicitQLearning:
         self._keep_grads = keep_grads
         self._handle = None
         self._handle_batch = None
+        self._group_owner = None  # the SeedGroup whose device-side group holds this trainer
         self._graph_unroll = 8
 
         if not isinstance(q_network, TwinQ) or not isinstance(v_network, ValueFunction) or \
@@ -607,6 +608,9 @@ class ImplicitQLearning:
 
     def _destroy_handle(self):
         if getattr(self, "_handle", None) is not None:
+            owner = getattr(self, "_group_owner", None)
+            if owner is not None:  # the device-side group refers to this handle: dissolve it first
+                owner._drop_group()
             torch.cuda.synchronize(self._dev)
             self._lib.iqlhip_trainer_destroy(self._handle)
             self._handle = None

@@ -1,43 +1,141 @@
-"""Several independent IQL seeds on ONE GPU, each on its own HIP stream.
+"""Several independent IQL seeds on ONE GPU.
 
 One seed at batch 256 is a latency chain that leaves most of an MI355X idle;
 the reference runs several W&B agents per GPU for the same reason
-(``ensemble_sweeps/launch.sh:12`` AGENTS_PER_GPU).  ``SeedGroup`` is that, inside one process:
-the trainers share nothing (own arenas, own Philox stream, own hipGraph), their launches
-interleave on separate streams, and the arithmetic of every seed is bit-identical to running
-it alone.
+(``ensemble_sweeps/launch.sh:12`` AGENTS_PER_GPU).  ``SeedGroup`` is that, inside one process.
+The trainers share nothing (own arenas, own Philox stream) and the arithmetic of every seed
+is bit-identical to running it alone.  Two execution modes:
+
+``mode="group"`` (default when the trainers have one shape)
+    ONE launch sequence steps all seeds: every kernel of the step runs with gridDim.y = K
+    (``iqlhip_group_train_steps``).  K x the work-groups per launch, one third of the kernel
+    boundaries per seed-step.
+``mode="streams"``
+    every trainer replays its own hipGraph on its own HIP stream; the launches interleave.
 """
+import ctypes as C
 from typing import List, Optional, Sequence, Union
 
 import torch
 
+from . import _lib
+from ._lib import check, ptr, stream_ptr
 from .iql import ImplicitQLearning, ReplayBuffer
 
 
+def _shape_key(t: ImplicitQLearning):
+    return (t._state_dim, t._action_dim, t._hidden, t._precision, t._deterministic, t._n_critics,
+            bool(t._dropout))
+
+
 class SeedGroup:
-    def __init__(self, trainers: Sequence[ImplicitQLearning], chunk: int = 2000):
+    def __init__(self, trainers: Sequence[ImplicitQLearning], chunk: int = 2000, mode: Optional[str] = None):
         if not trainers:
             raise ValueError("SeedGroup needs at least one trainer")
         devs = {t._dev for t in trainers}
         if len(devs) != 1:
             raise ValueError("all trainers of a SeedGroup must live on one device")
+        if len({id(t) for t in trainers}) != len(trainers):
+            raise ValueError("a trainer may appear only once in a SeedGroup")
+        one_shape = len({_shape_key(t) for t in trainers}) == 1 and len(trainers) <= _lib.MAX_GROUP
+        if mode is None:
+            mode = "group" if one_shape else "streams"
+        if mode not in ("group", "streams"):
+            raise ValueError("mode must be 'group' or 'streams'")
+        if mode == "group" and not one_shape:
+            raise ValueError(f"mode='group' needs at most {_lib.MAX_GROUP} trainers of one shape (dims, hidden, "
+                             "precision, policy kind, critics, dropout on/off)")
+        self.mode = mode
         self.trainers: List[ImplicitQLearning] = list(trainers)
         self._dev = next(iter(devs))
-        self._streams = [torch.cuda.Stream(device=self._dev) for _ in self.trainers]
+        self._lib = _lib.load()
+        self._streams = [torch.cuda.Stream(device=self._dev) for _ in self.trainers] if mode == "streams" else []
         self._chunk = int(chunk)
+        self._group = None
+        self._group_batch = None
 
     def __len__(self):
         return len(self.trainers)
 
+    # -- group handle --------------------------------------------------------- #
+    def _ensure_group(self, batch_size: int):
+        if self._group is not None and self._group_batch == batch_size and \
+                all(t._handle is not None and t._handle_batch == batch_size for t in self.trainers):
+            return
+        self._drop_group()
+        for t in self.trainers:
+            t._ensure_handle(batch_size)
+        arr = (C.c_void_p * len(self.trainers))(*[t._handle.value for t in self.trainers])
+        g = C.c_void_p()
+        with torch.cuda.device(self._dev):
+            check(self._lib.iqlhip_group_create(C.byref(g), arr, len(self.trainers)))
+        self._group, self._group_batch = g, batch_size
+        for t in self.trainers:
+            t._group_owner = self
+
+    def _drop_group(self):
+        if getattr(self, "_group", None) is not None:
+            self._lib.iqlhip_group_destroy(self._group)
+            self._group = None
+            for t in self.trainers:
+                t._group_owner = None
+
+    def close(self):
+        """Dissolve the device-side group; the trainers stay usable on their own."""
+        self._drop_group()
+
+    def __del__(self):
+        try:
+            self._drop_group()
+        except Exception:
+            pass
+
+    # -- stepping ------------------------------------------------------------- #
     def train_steps(self, replay: Union[ReplayBuffer, Sequence[ReplayBuffer]], n_steps: int, batch_size: int, *,
+                    indices: Optional[Sequence[Optional[torch.Tensor]]] = None,
+                    dropout_keep: Optional[Sequence[Optional[torch.Tensor]]] = None,
                     return_losses: bool = False, graph_unroll: Optional[int] = None):
         """``n_steps`` x (sample + train) for every seed.  ``replay`` is one buffer shared by all
-        seeds (a sweep varies the seed only) or one per seed.  Returns a list of [n_steps, 3]
-        loss tensors when ``return_losses``.  Asynchronous: call ``synchronize()`` (or read the
-        losses) before touching the parameters."""
-        bufs = list(replay) if isinstance(replay, (list, tuple)) else [replay] * len(self.trainers)
-        if len(bufs) != len(self.trainers):
+        seeds (a sweep varies the seed only) or one per seed; ``indices`` / ``dropout_keep`` are
+        optional per-seed lists (entries may be None) with the meaning of
+        ``ImplicitQLearning.train_steps``.  Returns a list of [n_steps, 3] loss tensors when
+        ``return_losses``.  Asynchronous: call ``synchronize()`` (or read the losses) before
+        touching the parameters."""
+        K = len(self.trainers)
+        bufs = list(replay) if isinstance(replay, (list, tuple)) else [replay] * K
+        if len(bufs) != K:
             raise ValueError("one replay buffer per trainer (or a single shared one)")
+        idx = list(indices) if indices is not None else [None] * K
+        keep = list(dropout_keep) if dropout_keep is not None else [None] * K
+        if len(idx) != K or len(keep) != K:
+            raise ValueError("indices / dropout_keep: one entry per trainer")
+        if self.mode == "streams":
+            return self._train_streams(bufs, n_steps, batch_size, idx, keep, return_losses, graph_unroll)
+        self._ensure_group(batch_size)
+        for i, t in enumerate(idx):
+            if t is not None:
+                if t.dtype != torch.int64 or tuple(t.shape) != (n_steps, batch_size):
+                    raise ValueError("indices must be int64 [n_steps, batch_size]")
+                idx[i] = t.contiguous()
+        keep = [None if k is None else k.to(torch.uint8).contiguous() for k in keep]
+        losses = [torch.empty((n_steps, 3), dtype=torch.float32, device=self._dev) for _ in range(K)] \
+            if return_losses else None
+        views = (_lib.ReplayView * K)(*[b.view() for b in bufs])
+        parr = lambda ts: (C.c_void_p * K)(*[None if t is None else t.data_ptr() for t in ts])
+        any_idx, any_keep = any(t is not None for t in idx), any(t is not None for t in keep)
+        for t in self.trainers:
+            t._refresh_lrs()
+        unroll = self.trainers[0]._graph_unroll if graph_unroll is None else graph_unroll
+        with torch.cuda.device(self._dev):
+            check(self._lib.iqlhip_group_train_steps(
+                self._group, views, n_steps, parr(idx) if any_idx else None,
+                parr(keep) if any_keep else None, parr(losses) if losses is not None else None,
+                unroll, stream_ptr()))
+        for t in self.trainers:
+            t._after_steps(n_steps)
+        return losses
+
+    def _train_streams(self, bufs, n_steps, batch_size, idx, keep, return_losses, graph_unroll):
         cur = torch.cuda.current_stream(self._dev)
         for st in self._streams:
             st.wait_stream(cur)
@@ -48,6 +146,8 @@ class SeedGroup:
             for k, (tr, st, buf) in enumerate(zip(self.trainers, self._streams, bufs)):
                 with torch.cuda.stream(st):
                     r = tr.train_steps(buf, c, batch_size, return_losses=return_losses,
+                                       indices=None if idx[k] is None else idx[k][done:done + c],
+                                       dropout_keep=None if keep[k] is None else keep[k][done:done + c],
                                        graph_unroll=graph_unroll)
                     if return_losses:
                         out[k].append(r)
@@ -61,3 +161,4 @@ class SeedGroup:
     def synchronize(self):
         for st in self._streams:
             st.synchronize()
+        torch.cuda.current_stream(self._dev).synchronize()

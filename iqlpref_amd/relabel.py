@@ -148,46 +148,55 @@ def modify_reward(dataset, env_name, normalize_reward, max_episode_steps=1000):
 # --------------------------------------------------------------------------- #
 # CVaR helpers  (ref:735-827)
 # --------------------------------------------------------------------------- #
+def _tail_count(alpha: float, n: int) -> int:
+    """Size of the CVaR tail of n samples at risk level alpha (ref:762, 935, 1152)."""
+    return max(1, int(np.floor((1.0 - alpha) * n)))
+
+
+def _tail_means(cols: np.ndarray, n_tail: int) -> np.ndarray:
+    """Mean of the n_tail smallest entries of every column of ``cols`` [S, C], summed in
+    ascending order in the input precision -- what ``np.sort(x)[:n_tail].mean()`` gives."""
+    part = np.partition(cols, n_tail - 1, axis=0)[:n_tail]
+    return np.sort(part, axis=0).mean(axis=0)
+
+
 def empirical_cvar(samples: np.ndarray, alpha: float) -> float:
+    """ref:735-763: mean of the worst (1 - alpha) fraction of the samples (at least one)."""
     if not (0.0 <= alpha < 1.0):
         raise ValueError(f"alpha must be in [0, 1), got {alpha!r}")
-    sorted_samples = np.sort(samples)
-    n_tail = max(1, int(np.floor((1.0 - alpha) * len(samples))))
-    return float(sorted_samples[:n_tail].mean())
+    x = np.asarray(samples).reshape(-1, 1)
+    return float(_tail_means(x, _tail_count(alpha, x.shape[0]))[0])
 
 
 def cvar_stability_check(all_preds, alpha: float, n_checks: int = 50,
                          remedy: str = "Increase bnn_n_samples") -> float:
-    """ref:766-827.  ``all_preds`` may be a device tensor [S, N]: only the
-    ``n_checks`` probed columns are copied to the host."""
+    """ref:766-827: CVaR from all S rows against CVaR from the first S // 2 rows on up to
+    ``n_checks`` columns drawn with ``default_rng(42)``; returns the mean relative gap and
+    warns above 0.05.  ``all_preds`` [S, N] may be a device tensor: the probed columns are
+    gathered on the device and only that [S, n_checks] block is copied to the host."""
     if alpha == 0.0:
         print("[CVaR stability] alpha=0 (posterior mean); stability check skipped")
         return 0.0
     S, N = all_preds.shape
-    rng = np.random.default_rng(seed=42)
-    indices = rng.choice(N, size=min(n_checks, N), replace=False)
+    probe = np.random.default_rng(seed=42).choice(N, size=min(n_checks, N), replace=False)
     if torch.is_tensor(all_preds):
-        cols = all_preds[:, torch.as_tensor(indices, device=all_preds.device)].cpu().numpy()
+        block = all_preds.index_select(1, torch.as_tensor(probe, device=all_preds.device)).cpu().numpy()
     else:
-        cols = all_preds[:, indices]
-    ratios = []
-    for j in range(len(indices)):
-        cvar_full = empirical_cvar(cols[:, j], alpha)
-        cvar_half = empirical_cvar(cols[: S // 2, j], alpha)
-        if abs(cvar_full) > 1e-8:
-            ratios.append(abs(cvar_full - cvar_half) / abs(cvar_full))
-    if not ratios:
+        block = np.asarray(all_preds)[:, probe]
+    full = _tail_means(block, _tail_count(alpha, S)).astype(np.float64)
+    half = (_tail_means(block[:S // 2], _tail_count(alpha, S // 2)).astype(np.float64) if S >= 2
+            else np.full(full.shape, np.nan))  # one sample: no half to compare with
+    usable = np.abs(full) > 1e-8
+    if not usable.any():
         return float("nan")
-    mean_ratio = float(np.mean(ratios))
-    status = "OK" if mean_ratio < 0.05 else "WARN"
-    print(f"[CVaR stability] mean relative diff = {mean_ratio:.3f} (target < 0.05) [{status}]")
-    if mean_ratio > 0.05:
-        min_s = int(np.ceil(30.0 / (1.0 - alpha)))
+    gap = float(np.mean(np.abs(full[usable] - half[usable]) / np.abs(full[usable])))
+    print(f"[CVaR stability] mean relative diff = {gap:.3f} (target < 0.05) [{'OK' if gap < 0.05 else 'WARN'}]")
+    if gap > 0.05:
         warnings.warn(
-            f"CVaR stability check: mean relative difference {mean_ratio:.3f} > 0.05. "
-            f"{remedy} (current S={S}). Recommended minimum for alpha={alpha}: S >= {min_s}.",
-            RuntimeWarning)
-    return mean_ratio
+            f"CVaR stability check: mean relative difference {gap:.3f} > 0.05. "
+            f"{remedy} (current S={S}). Recommended minimum for alpha={alpha}: "
+            f"S >= {int(np.ceil(30.0 / (1.0 - alpha)))}.", RuntimeWarning)
+    return gap
 
 
 def cvar_tail_mean_device(preds: torch.Tensor, n_tail: int) -> torch.Tensor:
@@ -252,43 +261,57 @@ class RewardMLP(nn.Module):
         return super().load_state_dict(own, strict=strict)
 
 
+_COMPILE_PREFIX = "_orig_mod."  # torch.compile wraps the module: every key gains this (ref:1312-1323)
+
+
+def _read_checkpoint(path: str, device) -> Dict[str, Any]:
+    """The ``net`` state dict of a reward-model checkpoint, keys as an uncompiled module writes
+    them.  Tensors only: the reference unpickles (weights_only=False); files this package did
+    not write are never unpickled."""
+    net = torch.load(path, map_location=device, weights_only=True)["net"]
+    return {k.removeprefix(_COMPILE_PREFIX): v for k, v in net.items()}
+
+
 def _strip_compile_prefix(state: Dict[str, Any]) -> Dict[str, Any]:
-    """ref:1312-1323"""
-    prefix = "_orig_mod."
-    return {(k[len(prefix):] if k.startswith(prefix) else k): v for k, v in state.items()}
+    return {k.removeprefix(_COMPILE_PREFIX): v for k, v in state.items()}
+
+
+_HIDDEN_W = re.compile(r"layers\.(?:0|linear_(\d+))\.W")
 
 
 def _build_mlp_reward_model(state: Dict[str, Any], activations: str, device: str = "cpu") -> nn.Module:
-    """ref:1326-1336"""
-    input_dim = state["layers.0.W"].shape[0]
-    hidden_dims = [state["layers.0.W"].shape[1]]
-    i = 1
-    while f"layers.linear_{i}.W" in state:
-        hidden_dims.append(state[f"layers.linear_{i}.W"].shape[1])
-        i += 1
-    return RewardMLP(input_dim, 1, hidden_dims, activations).to(device)
+    """ref:1326-1336: the architecture is read off the hidden weight shapes ([in, out] each):
+    layers.0.W, then layers.linear_1.W, layers.linear_2.W, ... for as long as they are present."""
+    by_depth = {}
+    for key, w in state.items():
+        m = _HIDDEN_W.fullmatch(key)
+        if m:
+            by_depth[int(m.group(1) or 0)] = w.shape
+    widths = []
+    while len(widths) in by_depth:
+        widths.append(by_depth[len(widths)][1])
+    return RewardMLP(by_depth[0][0], 1, widths, activations).to(device)
+
+
+def _run_config(model_dir: str) -> Dict[str, Any]:
+    with open(os.path.join(model_dir, "config.yaml")) as f:
+        return yaml.safe_load(f) or {}
 
 
 def _mr_activations(model_dir: str) -> str:
-    with open(os.path.join(model_dir, "config.yaml")) as f:
-        cfg = yaml.safe_load(f)
-    return cfg.get("activations", "relu")
+    return _run_config(model_dir).get("activations", "relu")
 
 
 def _torch_load(path, device):
-    # tensors only: the reference uses weights_only=False; checkpoints we did not
-    # write ourselves are never unpickled
     return torch.load(path, map_location=device, weights_only=True)
 
 
 def load_mlp_reward_model(model_dir: str, device: str = "cpu") -> nn.Module:
-    """ref:1345-1353"""
-    ckpt = _torch_load(os.path.join(model_dir, "best_model.pt"), device)
-    state = _strip_compile_prefix(ckpt["net"])
+    """ref:1345-1353: ``best_model.pt`` + ``config.yaml`` of an MR run directory."""
+    state = _read_checkpoint(os.path.join(model_dir, "best_model.pt"), device)
     model = _build_mlp_reward_model(state, _mr_activations(model_dir), device)
     model.load_state_dict(state)
-    model.eval()
-    return model
+    return model.eval()
 
 
 def _max_steps(env):
@@ -334,7 +357,7 @@ def _ensemble_rewards(weight_sets, activation, obs_act_t, alpha, label, remedy):
     """S forwards into a device [S, N-1] matrix, then the tail mean kernel."""
     S, n = len(weight_sets), obs_act_t.shape[0]
     dev = obs_act_t.device
-    n_tail = max(1, int(np.floor((1.0 - alpha) * S)))
+    n_tail = _tail_count(alpha, S)
     all_preds = torch.empty((S, n), dtype=torch.float32, device=dev)
     hidden_act = 0 if activation == "relu" else 1
     for k, (ws, bs) in enumerate(weight_sets):
@@ -352,27 +375,33 @@ def _ensemble_rewards(weight_sets, activation, obs_act_t, alpha, label, remedy):
     return pr.astype(np.float32)
 
 
+_SNAPSHOT = re.compile(r"checkpoint_(\d+)\.pt")
+
+
 def _discover_mr_snapshots(reward_model_dir: str, burn_in: int = 0) -> List[str]:
-    """ref:1047-1082"""
-    paths = _glob.glob(os.path.join(reward_model_dir, "checkpoint_*.pt"))
-    epoch_re = re.compile(r"checkpoint_(\d+)\.pt$")
-    found: List[Tuple[int, str]] = []
-    for p in paths:
-        m = epoch_re.search(os.path.basename(p))
-        if m is not None:
-            found.append((int(m.group(1)), p))
-    if not found:
+    """ref:1047-1082: the per-epoch ``checkpoint_{epoch}.pt`` files of an MR run, by epoch,
+    epochs below ``burn_in`` dropped (``best_model.pt`` duplicates one of them and is not a
+    member).  Same errors as the reference: no snapshot at all -> FileNotFoundError, a burn-in
+    that leaves none -> ValueError."""
+    epochs: Dict[int, str] = {}
+    if os.path.isdir(reward_model_dir):
+        with os.scandir(reward_model_dir) as it:
+            for entry in it:
+                m = _SNAPSHOT.fullmatch(entry.name)
+                if m:
+                    epochs[int(m.group(1))] = entry.path
+    if not epochs:
         raise FileNotFoundError(
             f"No MR snapshots found in {reward_model_dir}. Expected per-epoch "
             "checkpoint_{epoch}.pt files written by run_mr_training.py with checkpoints_path set.")
-    kept = sorted((e, p) for e, p in found if e >= burn_in)
-    if not kept:
-        max_epoch = max(e for e, _ in found)
-        raise ValueError(f"mr_burn_in={burn_in} discarded all {len(found)} snapshot(s) in "
-                         f"{reward_model_dir} (highest epoch present: {max_epoch}).")
-    if len(kept) < len(found):
-        print(f"[MR/CVaR] Burn-in {burn_in}: dropped {len(found) - len(kept)} snapshot(s) below epoch {burn_in}")
-    return [p for _, p in kept]
+    members = [epochs[e] for e in sorted(epochs) if e >= burn_in]
+    if not members:
+        raise ValueError(f"mr_burn_in={burn_in} discarded all {len(epochs)} snapshot(s) in "
+                         f"{reward_model_dir} (highest epoch present: {max(epochs)}).")
+    if len(members) < len(epochs):
+        print(f"[MR/CVaR] Burn-in {burn_in}: dropped {len(epochs) - len(members)} snapshot(s) "
+              f"below epoch {burn_in}")
+    return members
 
 
 def qlearning_dataset_mr_ensemble(env, reward_model_dir: str, alpha: float = 0.95, burn_in: int = 0,
@@ -387,7 +416,7 @@ def qlearning_dataset_mr_ensemble(env, reward_model_dir: str, alpha: float = 0.9
                                   terminate_on_end)
     ckpt_paths = _discover_mr_snapshots(reward_model_dir, burn_in)
     n_total = len(ckpt_paths)
-    n_tail = max(1, int(np.floor((1.0 - alpha) * n_total)))
+    n_tail = _tail_count(alpha, n_total)
     if n_tail < 5 and alpha > 0.0:
         warnings.warn(f"CVaR tail has only {n_tail} snapshot(s) with alpha={alpha} and S={n_total}. "
                       "Lower mr_alpha or train the reward model with more eval epochs.", RuntimeWarning)
@@ -395,7 +424,7 @@ def qlearning_dataset_mr_ensemble(env, reward_model_dir: str, alpha: float = 0.9
     activations = _mr_activations(reward_model_dir)
     sets = []
     for p in ckpt_paths:
-        state = _strip_compile_prefix(_torch_load(p, dev)["net"])
+        state = _read_checkpoint(p, dev)
         net = _build_mlp_reward_model(state, activations, dev)
         net.load_state_dict(state)
         sets.append(net.wb())
@@ -436,7 +465,7 @@ def qlearning_dataset_bnn(env, reward_model_dir: str, alpha: float = 0.95, n_sam
         idx = rng.choice(available, size=n_samples, replace=False)
         all_weights = [all_weights[i] for i in sorted(idx)]
     n_total = len(all_weights)
-    n_tail = max(1, int(np.floor((1.0 - alpha) * n_total)))
+    n_tail = _tail_count(alpha, n_total)
     if n_tail < 5:
         warnings.warn(f"CVaR tail has only {n_tail} sample(s) with alpha={alpha} and S={n_total}.",
                       RuntimeWarning)
@@ -559,31 +588,33 @@ class RewardPT(nn.Module):
 
 
 def load_pt_reward_model(model_dir: str, device: str = "cpu") -> nn.Module:
-    """ref:1356-1390"""
-    with open(os.path.join(model_dir, "config.yaml")) as f:
-        cfg = yaml.safe_load(f)
-    ckpt = _torch_load(os.path.join(model_dir, "best_model.pt"), device)
-    state = _strip_compile_prefix(ckpt["net"])
-    state_dim = state["state_linear.weight"].shape[1]
-    action_dim = state["action_linear.weight"].shape[1]
-    embd_dim = state["state_linear.weight"].shape[0]
-    max_episode_steps = state["timestep_embed.weight"].shape[0] - 1
-    pref_attn_embd_dim = (state["pref_linear.weight"].shape[0] - 1) // 2
-    num_layers = 0
-    while f"gpt.layers.{num_layers}.layer_norm_0.weight" in state:
-        num_layers += 1
-    max_pos = state["gpt.layers.0.attention.causal_bias"].shape[2]
-    intermediate_dim = cfg.get("intermediate_dim") or (4 * embd_dim)
-    model = RewardPT(
-        state_dim=state_dim, action_dim=action_dim, max_episode_steps=max_episode_steps,
-        embd_dim=embd_dim, pref_attn_embd_dim=pref_attn_embd_dim, num_heads=cfg.get("num_heads", 4),
-        attn_dropout=cfg.get("attn_dropout", 0.1), resid_dropout=cfg.get("resid_dropout", 0.1),
-        intermediate_dim=intermediate_dim, num_layers=num_layers,
-        embd_dropout=cfg.get("embd_dropout", 0.1), max_pos=max_pos, eps=cfg.get("model_eps", 1e-5),
-    ).to(device)
+    """ref:1356-1390: every size comes from a tensor shape of ``best_model.pt``; what no shape
+    shows (heads, dropouts, MLP width, LayerNorm eps) comes from the run's ``config.yaml`` with
+    the reference's fall-backs."""
+    cfg = _run_config(model_dir)
+    state = _read_checkpoint(os.path.join(model_dir, "best_model.pt"), device)
+    shape = lambda key: tuple(state[key].shape)
+    embd_dim, state_dim = shape("state_linear.weight")
+    depth = 0
+    while f"gpt.layers.{depth}.layer_norm_0.weight" in state:
+        depth += 1
+    arch = dict(
+        state_dim=state_dim,
+        action_dim=shape("action_linear.weight")[1],
+        max_episode_steps=shape("timestep_embed.weight")[0] - 1,
+        embd_dim=embd_dim,
+        pref_attn_embd_dim=(shape("pref_linear.weight")[0] - 1) // 2,
+        num_layers=depth,
+        max_pos=shape("gpt.layers.0.attention.causal_bias")[2],
+        intermediate_dim=cfg.get("intermediate_dim") or 4 * embd_dim,
+        num_heads=cfg.get("num_heads", 4),
+        eps=cfg.get("model_eps", 1e-5),
+    )
+    for rate in ("attn_dropout", "resid_dropout", "embd_dropout"):
+        arch[rate] = cfg.get(rate, 0.1)
+    model = RewardPT(**arch).to(device)
     model.load_state_dict(state)
-    model.eval()
-    return model
+    return model.eval()
 
 
 def qlearning_dataset_pt(env, r_model, query_length=100, dataset=None, terminate_on_end=False,

@@ -11,7 +11,7 @@ import os
 import time
 from dataclasses import asdict
 from pathlib import Path
-from typing import Callable, Dict, List, Optional, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -23,69 +23,112 @@ from .relabel import (load_mlp_reward_model, load_pt_reward_model, modify_reward
                       qlearning_dataset_mr, qlearning_dataset_mr_ensemble, qlearning_dataset_pt)
 
 
+class _NormalizedEnv:
+    """What the reference builds from gym.wrappers.TransformObservation / TransformReward
+    (ref:140-161), without importing gym: observations are z-scored with the dataset
+    statistics on the way out of reset() / step(), rewards are scaled.  Everything else is the
+    wrapped environment's."""
+
+    def __init__(self, env, state_mean, state_std, reward_scale):
+        self.env = env
+        self._mean, self._std, self._scale = state_mean, state_std, reward_scale
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def _obs(self, obs):
+        return (obs - self._mean) / self._std  # the epsilon is already part of state_std
+
+    def reset(self, **kw):
+        out = self.env.reset(**kw)
+        return (self._obs(out[0]),) + tuple(out[1:]) if isinstance(out, tuple) else self._obs(out)
+
+    def step(self, action):
+        obs, reward, *rest = self.env.step(action)
+        return (self._obs(obs), reward * self._scale if self._scale != 1.0 else reward, *rest)
+
+
 def wrap_env(env, state_mean=0.0, state_std=1.0, reward_scale: float = 1.0):
-    """ref:140-161"""
+    """ref:140-161: normalised observations (and scaled rewards) around ``env``."""
+    return _NormalizedEnv(env, state_mean, state_std, reward_scale)
+
+
+def _gym_vector_env(env_name: str, seeds: Sequence[int], state_mean, state_std):
+    """Default evaluation back end: one gym environment per seed in its own subprocess
+    (ref:289-295 AsyncVectorEnv).  gym / d4rl are imported only here."""
     import gym
 
-    def normalize_state(state):
-        return (state - state_mean) / state_std
+    def make(seed):
+        def thunk():
+            env = wrap_env(gym.make(env_name), state_mean=state_mean, state_std=state_std)
+            env.seed(seed)
+            return env
+        return thunk
 
-    def scale_reward(reward):
-        return reward_scale * reward
+    return gym.vector.AsyncVectorEnv([make(s) for s in seeds])
 
-    env = gym.wrappers.TransformObservation(env, normalize_state)
-    if reward_scale != 1.0:
-        env = gym.wrappers.TransformReward(env, scale_reward)
-    return env
+
+def policy_actions(actor, obs, max_action: float, device) -> np.ndarray:
+    """Greedy actions for a batch of observations [n, S]: ONE exact-fp32 MLP forward on the GPU
+    for all environments (iqlhip_mlp_forward), tanh mean scaled and clamped to the action box
+    (ref:306-319; the Gaussian policy is evaluated at its mean, ref:309)."""
+    states = torch.as_tensor(np.asarray(obs), dtype=torch.float32, device=device)
+    mean = actor.net(states)
+    return torch.clamp(max_action * mean, -max_action, max_action).cpu().numpy()
+
+
+class EpisodeLedger:
+    """Episode accounting of ref:296-333 for ``n_envs`` environments stepped in lock step:
+    running return and length per environment, returns of finished episodes in the order
+    (step, environment index), lengths of the successful antmaze episodes (return > 0.5:
+    the goal pays a sparse 1)."""
+
+    def __init__(self, n_envs: int, n_episodes: int, goal_env: bool):
+        self.ret = np.zeros(n_envs, dtype=np.float64)
+        self.length = np.zeros(n_envs, dtype=np.int64)
+        self.scores: List[float] = []
+        self.steps_to_goal: List[int] = []
+        self._want, self._goal_env = n_episodes, goal_env
+
+    @property
+    def full(self) -> bool:
+        return len(self.scores) >= self._want
+
+    def record(self, rewards, dones) -> None:
+        self.ret += np.asarray(rewards, dtype=np.float64)
+        self.length += 1
+        ended = np.flatnonzero(np.asarray(dones))[:self._want - len(self.scores)]
+        self.scores.extend(self.ret[ended].tolist())
+        if self._goal_env:
+            self.steps_to_goal.extend(int(n) for n in self.length[ended][self.ret[ended] > 0.5])
+        self.ret[ended] = 0.0
+        self.length[ended] = 0
 
 
 @torch.inference_mode()
 def eval_actor(env_name: str, actor, max_action: float, state_mean, state_std, device: str,
-               n_episodes: int, seed: int, n_envs: int = 25, make_env: Optional[Callable] = None
-               ) -> Tuple[np.ndarray, List[int]]:
-    """ref:265-341: ``n_envs`` parallel episodes, batched actor inference on the GPU
-    (one iqlhip_mlp_forward per env step for all envs)."""
-    import gym
-    from functools import partial
+               n_episodes: int, seed: int, n_envs: int = 25, *,
+               vector_env: Optional[Callable] = None) -> Tuple[np.ndarray, List[int]]:
+    """ref:265-341.  ``n_envs`` environments run in lock step until ``n_episodes`` episodes have
+    finished; every step is one batched actor forward on the GPU.  Returns (episode returns
+    [n_episodes], steps-to-goal of the successful antmaze episodes).
 
-    is_antmaze = "antmaze" in env_name.lower()
+    ``vector_env(env_name, seeds, state_mean, state_std)`` builds the environments (default:
+    gym's AsyncVectorEnv over ``gym.make``); it must offer ``reset() -> obs [n, S]``,
+    ``step(actions [n, A]) -> (obs, rewards, dones, infos)`` with auto-reset, and ``close()``."""
     n_envs = min(n_envs, n_episodes)
-
-    def _make(i):
-        e = make_env(env_name) if make_env else gym.make(env_name)
-        e = wrap_env(e, state_mean=state_mean, state_std=state_std)
-        e.seed(seed + i)
-        return e
-
-    vec_env = gym.vector.AsyncVectorEnv([partial(_make, i) for i in range(n_envs)])
+    envs = (vector_env or _gym_vector_env)(env_name, [seed + i for i in range(n_envs)], state_mean, state_std)
+    ledger = EpisodeLedger(n_envs, n_episodes, goal_env="antmaze" in env_name.lower())
     actor.eval()
-    obs = vec_env.reset()
-    ep_rewards = np.zeros(n_envs, dtype=np.float64)
-    ep_steps = np.zeros(n_envs, dtype=np.int64)
-    completed: List[float] = []
-    steps_to_goal: List[int] = []
     try:
-        while len(completed) < n_episodes:
-            states_t = torch.tensor(obs, dtype=torch.float32, device=device)
-            out = actor(states_t)
-            mean = out.mean if isinstance(out, torch.distributions.Distribution) else out
-            actions = torch.clamp(max_action * mean, -max_action, max_action).cpu().numpy()
-            obs, rewards, dones, _ = vec_env.step(actions)
-            ep_rewards += rewards
-            ep_steps += 1
-            for i in range(n_envs):
-                if dones[i]:
-                    if is_antmaze and ep_rewards[i] > 0.5:
-                        steps_to_goal.append(int(ep_steps[i]))
-                    completed.append(float(ep_rewards[i]))
-                    ep_rewards[i] = 0.0
-                    ep_steps[i] = 0
-                    if len(completed) >= n_episodes:
-                        break
+        obs = envs.reset()
+        while not ledger.full:
+            obs, rewards, dones, _ = envs.step(policy_actions(actor, obs, max_action, device))
+            ledger.record(rewards, dones)
     finally:
-        vec_env.close()
-    actor.train()
-    return np.asarray(completed[:n_episodes]), steps_to_goal
+        envs.close()
+        actor.train()  # ref:340: the reference always hands the actor back in train mode
+    return np.asarray(ledger.scores[:n_episodes]), ledger.steps_to_goal
 
 
 def build_dataset(config: TrainConfig, env, dataset=None) -> Dict[str, np.ndarray]:

@@ -319,3 +319,30 @@ def make_pt_params(rng, state_dim, action_dim, max_episode_steps, embd=64, pref=
     ln("gpt.layer_norm")
     lin("pref_linear", 2 * pref + 1, embd)
     return p
+
+
+# --------------------------------------------------------------------------- #
+# eval_actor's episode accounting  (ref:296-333), as the reference loops it
+# --------------------------------------------------------------------------- #
+def eval_accounting(steps, n_envs, n_episodes, is_antmaze):
+    """``steps`` = iterable of (rewards[n_envs], dones[n_envs]) as ``vec_env.step`` returns them.
+    Returns (scores[n_episodes], steps_to_goal, number of environment steps consumed)."""
+    ep_rewards = np.zeros(n_envs, dtype=np.float64)
+    ep_steps = np.zeros(n_envs, dtype=np.int64)
+    completed, steps_to_goal, used = [], [], 0
+    it = iter(steps)
+    while len(completed) < n_episodes:            # ref:304
+        rewards, dones = next(it)
+        used += 1
+        ep_rewards += rewards                      # ref:321
+        ep_steps += 1                              # ref:322
+        for i in range(n_envs):                    # ref:324
+            if dones[i]:
+                if is_antmaze and ep_rewards[i] > 0.5:   # ref:328
+                    steps_to_goal.append(int(ep_steps[i]))
+                completed.append(float(ep_rewards[i]))   # ref:330
+                ep_rewards[i] = 0.0
+                ep_steps[i] = 0
+                if len(completed) >= n_episodes:          # ref:333
+                    break
+    return np.asarray(completed[:n_episodes]), steps_to_goal, used

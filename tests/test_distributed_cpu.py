@@ -12,6 +12,9 @@ import os, sys, json
 sys.path.insert(0, sys.argv[1])
 import torch.distributed as dist
 from iqlpref_amd import distributed as D
+# rank -> GPU mapping (pure part; there is no GPU here, so local_device() binds nothing)
+assert D.device_for_rank(int(os.environ["LOCAL_RANK"]), 8) == "cuda:" + os.environ["LOCAL_RANK"]
+assert D.local_device() is None
 rank = D.init_from_env(backend="gloo")
 assert dist.get_world_size() == 2
 seed = D.rank_seed(10)
@@ -53,3 +56,23 @@ def test_single_process_gather_is_identity():
     from iqlpref_amd import distributed as D
     recs = D.gather_metrics({"seed": 3, "total_it": 7, "q_loss": 1.5})
     assert len(recs) == 1 and recs[0]["seed"] == 3.0 and recs[0]["q_loss"] == 1.5 and recs[0]["rank"] == 0.0
+
+
+def test_rank_to_gpu_mapping():
+    """One process per GPU: rank r owns cuda:r; more local ranks than GPUs is an error, never a
+    silent share of GPU 0 (train() under torchrun bound every rank to cuda:0)."""
+    import pytest
+    from iqlpref_amd import distributed as D
+    assert [D.device_for_rank(r, 8) for r in range(8)] == [f"cuda:{r}" for r in range(8)]
+    with pytest.raises(RuntimeError, match="one rank per GPU"):
+        D.device_for_rank(1, 1)
+    assert D.local_device() is None  # WORLD_SIZE unset: not a multi-rank job
+
+
+def test_bench_refuses_fewer_gpus_than_asked(tmp_path):
+    """bench.py --gpus 2 from plain `python` starts the ranks itself; with fewer visible GPUs it
+    exits non-zero instead of benchmarking one rank (no GPU here: 0 visible)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
+                        "--warmup", "5"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "only 0 GPU(s) are visible" in p.stderr and p.stdout.strip() == ""

@@ -125,15 +125,20 @@ def test_mr_ensemble_matches_reference(g, tmp_path, alpha, burn):
         ia.qlearning_dataset_mr_ensemble(FakeEnv(15), str(tmp_path / "nope"), device=DEV, dataset=ds)
 
 
+@pytest.mark.parametrize("as_numpy", [True, False])
 @pytest.mark.parametrize("alpha,ns", [(0.5, 500), (0.75, 5), (0.0, 0)])
-def test_bnn_matches_reference(g, tmp_path, alpha, ns):
+def test_bnn_matches_reference(g, tmp_path, alpha, ns, as_numpy):
+    """as_numpy: the posterior files hold lists of NUMPY arrays -- the form the reference's sampler
+    writes and ref:913-915 reads (and the form tests/golden/make_fixtures.py gave the reference);
+    otherwise lists of tensors."""
     import warnings
     import iqlpref_amd as ia
     all_w = [[g[f"g5/bnn/w{i}/{j}"] for j in range(6)] for i in range(8)]
     for c in range(2):
         cdir = tmp_path / "sampling_f" / f"chain_{c}" / "sampled_weights"
         os.makedirs(cdir)
-        torch.save({"sampled_weights": [[torch.from_numpy(a) for a in w] for w in all_w[4 * c:4 * c + 4]]},
+        conv = (lambda a: np.array(a)) if as_numpy else torch.from_numpy
+        torch.save({"sampled_weights": [[conv(a) for a in w] for w in all_w[4 * c:4 * c + 4]]},
                    cdir / "sampled_weights_0000000")
     ds = g5_dataset(g)
     with warnings.catch_warnings():

@@ -7,6 +7,7 @@ import re
 
 import numpy as np
 import pytest
+import torch
 
 from oracle import relabel_oracle as ro
 from tests import helpers
@@ -151,3 +152,76 @@ def test_no_cpu_path():
     import iqlpref_amd as ia
     with pytest.raises(RuntimeError, match="no CPU path"):
         ia.ReplayBuffer(3, 2, 10, "cpu")
+
+
+def test_build_tag_ties_library_to_sources():
+    """The library carries the hash of the sources it was built from; the binding refuses another."""
+    from iqlpref_amd import _lib, build
+    assert build.built_tag() == build.source_tag() == _lib.build_tag()
+    assert len(_lib.build_tag()) == 16 and not build.needs_build()
+    assert build.source_tag(["-DX"]) != build.source_tag()
+
+
+def test_snapshot_discovery_matches_reference(g, tmp_path):
+    import iqlpref_amd as ia
+    from iqlpref_amd import relabel
+    # the directory the reference was given when the golden was recorded (make_fixtures.py):
+    # checkpoint_0..5.pt + best_model.pt, burn-in 2
+    ref_dir = tmp_path / "as_recorded"
+    ref_dir.mkdir()
+    for name in [f"checkpoint_{e}.pt" for e in range(6)] + ["best_model.pt"]:
+        (ref_dir / name).write_bytes(b"")
+    got = [os.path.basename(p) for p in relabel._discover_mr_snapshots(str(ref_dir), 2)]
+    assert got == [str(x) for x in g["g5/ens/discovered_burn2"]]
+    # numeric (not lexicographic) epoch order, and only exact checkpoint_<digits>.pt names
+    for name in ("checkpoint_0.pt", "checkpoint_1.pt", "checkpoint_2.pt", "checkpoint_3.pt", "checkpoint_10.pt",
+                 "best_model.pt", "checkpoint_x.pt", "checkpoint_4.pt.bak", "xcheckpoint_5.pt"):
+        (tmp_path / name).write_bytes(b"")
+    found = relabel._discover_mr_snapshots(str(tmp_path), 2)
+    assert [os.path.basename(p) for p in found] == ["checkpoint_2.pt", "checkpoint_3.pt", "checkpoint_10.pt"]
+    with pytest.raises(ValueError, match="discarded all 5"):
+        relabel._discover_mr_snapshots(str(tmp_path), 11)
+    with pytest.raises(FileNotFoundError, match="No MR snapshots"):
+        relabel._discover_mr_snapshots(str(tmp_path / "missing"))
+
+
+def test_bnn_weight_file_with_numpy_arrays(tmp_path):
+    """The reference's posterior files hold lists of numpy arrays (ref:905-915); they are read
+    with the restricted unpickler plus an allow-list for ndarray reconstruction."""
+    from iqlpref_amd import relabel
+    rng = np.random.default_rng(0)
+    ws = [[rng.standard_normal(s).astype(np.float32) for s in ((5, 8), (8,), (8, 1), (1,))] for _ in range(3)]
+    f = tmp_path / "sampled_weights_0000000"
+    torch.save({"sampled_weights": ws}, f)
+    got = relabel.load_bnn_weight_file(str(f))["sampled_weights"]
+    assert len(got) == 3 and all(isinstance(a, np.ndarray) for w in got for a in w)
+    for w, g_ in zip(ws, got):
+        for a, b in zip(w, g_):
+            np.testing.assert_array_equal(a, b)
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    torch.save({"sampled_weights": [Evil()]}, f)
+    with pytest.raises(Exception):  # anything outside the allow-list is refused, not executed
+        relabel.load_bnn_weight_file(str(f))
+
+
+@pytest.mark.parametrize("goal_env", [True, False])
+def test_episode_ledger_matches_reference_loop(goal_env):
+    """EpisodeLedger (iqlpref_amd/train.py) against the reference's per-environment loop
+    (ref:296-333), restated in oracle/relabel_oracle.py."""
+    from iqlpref_amd.train import EpisodeLedger
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        n_envs, n_eps = int(rng.integers(1, 7)), int(rng.integers(1, 30))
+        steps = [(rng.uniform(-0.2, 0.4, n_envs), rng.uniform(size=n_envs) < 0.3) for _ in range(400)]
+        led = EpisodeLedger(n_envs, n_eps, goal_env)
+        used = 0
+        while not led.full:
+            led.record(*steps[used])
+            used += 1
+        scores, goal, used_ref = ro.eval_accounting(steps, n_envs, n_eps, goal_env)
+        assert used == used_ref
+        np.testing.assert_array_equal(np.asarray(led.scores[:n_eps]), scores)
+        assert led.steps_to_goal == goal
