@@ -15,8 +15,7 @@
 #include "iql_step.h"
 
 namespace iqlhip {
-size_t fwd_smem_bytes(bool bf16, int H, int k1max);
-size_t bwd_smem_bytes(bool bf16, int H);
+int layer2_parts(int H);
 hipError_t launch_forward(bool, const TrainerDesc &, const TrainerDesc *, const DevArgs *, const DevCtr *,
                           int n_seeds, hipStream_t);
 hipError_t launch_backward(bool, const TrainerDesc &, const TrainerDesc *, const DevArgs *, DevCtr *,
@@ -319,7 +318,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   add((size_t)NT * H * D.BP * es);
   add((size_t)NT * H * D.BP * es);
   add((size_t)NT * D.opmax * D.BP * es);
-  add((size_t)B * D.OUTW * 4);
+  add((size_t)layer2_parts(H) * B * D.OUTW * 4);
   add((size_t)NT * (B / 16) * 4);
   add((size_t)(B / 16) * A * 4);
   add((size_t)A * 4);
@@ -407,7 +406,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   D.dz1T = carve<char>(p, (size_t)NT * H * D.BP * es);
   D.dz2T = carve<char>(p, (size_t)NT * H * D.BP * es);
   D.dz3T = carve<char>(p, (size_t)NT * D.opmax * D.BP * es);
-  D.outs = carve<float>(p, (size_t)B * D.OUTW);
+  D.outs = carve<float>(p, (size_t)layer2_parts(H) * B * D.OUTW);
   D.lossp = carve<float>(p, (size_t)NT * (B / 16));
   D.lsp = carve<float>(p, (size_t)(B / 16) * A);
   D.ls_snap = carve<float>(p, (size_t)A);

@@ -63,7 +63,8 @@ struct TrainerDesc {
   void *dz1T;     // [ntrain][H][B]
   void *dz2T;     // [ntrain][H][B]
   void *dz3T;     // [ntrain][opmax][B]
-  float *outs;    // [B][OUTW]
+  float *outs;    // [SPL][B][OUTW] forward outputs as partial dot products, one plane per part
+                  // of hidden layer 2 (SPL = 4 at H = 256); summed by k_backward (fin_value)
   float *lossp;   // [ntrain][nslab]   per-slab loss partial sums
   float *lsp;     // [nslab][A]   per-slab d(loss)/d(std) partial sums
   float *ls_snap; // [A] log_std as of the start of the step (written by k_forward's spare block)

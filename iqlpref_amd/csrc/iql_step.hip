@@ -334,33 +334,62 @@ __device__ __forceinline__ void write_adam_coef(const TrainerDesc &D, const DevA
 
 // ========================================================================
 // k_forward
+//
+// One work-group = (evaluation, slab of 16*MT batch rows, part of layer 2).  Layer 2's output
+// features are split into SPL parts of 64 (one 16-column tile per wave): a work-group streams
+// all of W1 (every part recomputes the cheap first layer), ONE part of W2 (H x 64) and the
+// matching K-slice of W3, i.e. 32 + 32 + 2 KB at H = 256 instead of the 160 KB of an unsplit
+// slab -- the per-CU fetch rate from L2 (~70 GB/s) is what bounds this kernel.  The output
+// layer therefore produces PARTIAL dot products per part (outs[part][row][col], the bias in
+// part 0); k_backward adds the parts in a fixed order (fin_outputs) -- deterministic.
+// Grid: (2E+3 evaluations + the spare job) x B/(16 MT) slabs x SPL parts; all work-groups
+// of an evaluation sit on one XCD (its weights are fetched into that L2 once).
 // ========================================================================
 template <bool BF16, int H>
+struct FCfg {
+  using P = Prec<BF16>;
+  static constexpr int TPW = H / 64;                  // layer-1 n-tiles per wave (4 waves cover H)
+  static constexpr int SPL = TPW >= 4 ? 4 : TPW;      // parts of layer 2 (H = 256: 4, 128: 2, 64: 1)
+  static constexpr int HQ = H / SPL;                  // layer-2 features per part (= 64: one tile per wave)
+  static constexpr int NK2 = H / P::KM;               // k-steps of layer 2 (K = H)
+  static constexpr int NK3 = HQ / P::KM;              // layer-3 k-steps of one part
+  static constexpr int NK1 = BF16 ? 4 : 8;            // layer-1 k-steps in registers (k1pad <= 128)
+  static constexpr int HP = H + P::EPV;               // LDS row strides: +16 B breaks bank conflicts
+  static constexpr int HQP = HQ + P::EPV;
+  static_assert(HQ == 64, "one 16-column tile per wave and part");
+};
+
+template <bool BF16, int H, int MT>
 __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__ Dp,
                                                  const DevArgs *__restrict__ Ap,
                                                  const DevCtr *__restrict__ Cp, const int nsl_,
                                                  const int nfwd_) {
+  using C = FCfg<BF16, H>;
   using P = Prec<BF16>;
   using T = typename P::T;
-  // blocks are dealt round-robin over the 8 XCDs: keep all slabs of one network on one
-  // XCD so its weights are fetched into that L2 once (speed only, never correctness).
-  // Job j (evaluation j < nfwd, or the spare job nfwd) lives on XCD j & 7, round j >> 3.
-  // (nsl_ = B / 16 and nfwd_ arrive as preloaded kernel arguments: the job index, and with it
-  // the address of this work-group's FwdNet, must not wait for a first descriptor load)
+  constexpr int ROWS = 16 * MT, TPW = C::TPW, SPL = C::SPL, HP = C::HP, HQP = C::HQP;
   // blockIdx.y = seed of a group launch (iqlhip_group_*): the descriptors of the seeds of a
   // group are contiguous arrays; a solo launch has gridDim.y = 1
   Dp += blockIdx.y, Ap += blockIdx.y, Cp += blockIdx.y;
+  // blocks are dealt round-robin over the 8 XCDs: job j (evaluation j < nfwd, or the spare job
+  // nfwd) lives on XCD j & 7, round j >> 3, with all its slabs and parts (speed only).
+  // (nsl_ = slabs of 16 MT rows and nfwd_ arrive as preloaded kernel arguments: the job index,
+  // and with it the address of this work-group's FwdNet, must not wait for a descriptor load)
   const TrainerDesc &D = *Dp;
   const int idx_ = blockIdx.x >> 3;
-  const int fnet = (idx_ / nsl_) * 8 + (blockIdx.x & 7), slab = idx_ % nsl_;
+  const int per_job = nsl_ * SPL;
+  const int fnet = (idx_ / per_job) * 8 + (blockIdx.x & 7);
+  const int rest = idx_ % per_job;
+  const int slab = rest / SPL;
+  const int part = __builtin_amdgcn_readfirstlane(rest % SPL);
   if (fnet > nfwd_) return;
   if (fnet == nfwd_) {
     // spare XCD slot: one thread prepares this step's Adam coefficients for k_update
-    if (slab == 0 && threadIdx.x == 0) {
+    if (rest == 0 && threadIdx.x == 0) {
       write_adam_coef(D, *Ap, Cp->ctr[0] + 1, const_cast<AdamCoef *>(&Cp->coef));
       const_cast<DevCtr *>(Cp)->coef_step = Cp->ctr[0] + 1;
     }
-    if (slab == 0 && !D.deterministic && (int)threadIdx.x < D.A)
+    if (rest == 0 && !D.deterministic && (int)threadIdx.x < D.A)
       stg(D.ls_snap + threadIdx.x, ldg(D.params + D.off_log_std + threadIdx.x));
     return;
   }
@@ -368,22 +397,39 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   const FwdNet N = D.fwd[fnet];
   const int64_t step = Cp->ctr[0];
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-uniform branches stay scalar
+  const int r = lane & 15, q = lane >> 4;
+  const int K1P = D.k1max + P::EPV;
+  T *xs = reinterpret_cast<T *>(smem);   // [ROWS][K1P]  layer-1 input
+  T *h1 = xs + ROWS * K1P;               // [ROWS][HP]   all of hidden layer 1
+  T *h2 = h1 + ROWS * HP;                // [ROWS][HQP]  this part of hidden layer 2
+  const int B = D.B;
+  STAMP(0, 0);
+  // everything the epilogues need from the descriptors joins the first batch of scalar loads
+  pin_s(D.hT), pin_s(D.BP), pin_s(N.train_slot), pin_s(N.dropout), pin_s(N.out_dim), pin_s(N.out_col);
+  pin_s(N.out_pad), pin_s(D.outs), pin_s(D.OUTW), pin_s(B);
 
-  // 16 lanes per row: batch index (ref:211-214), then the row's input segment
-  const int rr = threadIdx.x >> 4, l16 = threadIdx.x & 15;
-  const int row = slab * SLAB + rr;
+  // ---- the input rows first: loads return in order, so the gather must not queue behind the
+  // weight fragments requested next.  16 lanes per row: batch index (ref:211-214), then the
+  // row's input segment; MT passes of 16 rows.  Rows beyond B (B % ROWS != 0) re-read row B-1
+  // and are never stored.
+  const int rr = tid >> 4, l16 = tid & 15;
   constexpr int NXV = 8;  // k1pad <= 128 -> at most 8 elements per lane
-  float xv[NXV], av[2], rdv = 0.f;
+  float xv[MT][NXV], av[MT][2], rdv[MT];
   // rows already gathered by the previous k_update's idle work-groups?
   const bool staged = D.stage_rows && Cp->staged_step == step && Cp->staged_call == A.call_id;
-  auto issue = [&]() {
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int row_ = slab * ROWS + 16 * m + rr;
+    const int row = row_ < B ? row_ : B - 1;
     const float *src;
     if (staged) {
       src = D.stage_rows + (size_t)row * D.stage_stride;
     } else {
       int64_t ix;
       if (A.idx_mode == 1)
-        ix = ldg(A.idx + (size_t)(step - A.base_step) * D.B + row);
+        ix = ldg(A.idx + (size_t)(step - A.base_step) * B + row);
       else if (A.idx_mode == 2)
         ix = row;
       else
@@ -397,35 +443,180 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
 #pragma unroll
     for (int j = 0; j < NXV; ++j) {
       const int c = l16 + 16 * j;
-      xv[j] = ldg(src + N.in_off + (c < N.in_dim ? c : N.in_dim - 1));
+      xv[m][j] = ldg(src + N.in_off + (c < N.in_dim ? c : N.in_dim - 1));
     }
+    rdv[m] = 0.f, av[m][0] = av[m][1] = 0.f;
     if (N.stage) {
-      rdv = ldg(src + D.S + D.A + (l16 & 1));
+      rdv[m] = ldg(src + D.S + D.A + (l16 & 1));
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int c = l16 + 16 * j;
-        av[j] = ldg(src + D.S + (c < D.A ? c : D.A - 1));
+        av[m][j] = ldg(src + D.S + (c < D.A ? c : D.A - 1));
       }
     }
-  };
-  auto fill = [&](T *xs, int K1P) {
+  }
+  // ---- request every weight fragment this wave will need, biases first: they are needed at
+  // the END of a layer and loads return in order ----
+  const int nk1 = N.k1pad / P::KM;
+  const int nt3 = N.out_pad / 16;  // 1 or 2
+  const int tile2 = part * 4 + wave;  // this wave's n-tile of layer 2 (of H / 16)
+  float bias1[TPW], bias3[2];
+#pragma unroll
+  for (int jj = 0; jj < TPW; ++jj) bias1[jj] = ldg(N.b1 + 16 * (wave * TPW + jj) + r);
+  const float bias2 = ldg(N.b2 + 16 * tile2 + r);
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)  // clamped (used for col < out_dim)
+    bias3[jt] = ldg(N.b3 + (16 * jt + r < N.out_dim ? 16 * jt + r : N.out_dim - 1));
+  uint4 w1[C::NK1][TPW], w2[C::NK2], w3[C::NK3][2];
+  const T *W1 = reinterpret_cast<const T *>(N.w1c);
+  const T *W2 = reinterpret_cast<const T *>(N.w2c);
+  const T *W3 = reinterpret_cast<const T *>(N.w3c);
+  load_w<P, C::NK1, TPW>(w1, W1, nk1, 0, nk1, wave * TPW, lane);
+#pragma unroll
+  for (int ks = 0; ks < C::NK2; ++ks) w2[ks] = ldg16(W2 + frag_off<P>(tile2, ks, C::NK2, lane));
+#pragma unroll
+  for (int ks = 0; ks < C::NK3; ++ks)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)  // unconditional (clamped): no branch, no drain of the queue
+      w3[ks][jt] = ldg16(W3 + frag_off<P>(jt < nt3 ? jt : 0, part * C::NK3 + ks, C::NK2, lane));
+  STAMP(0, 1);
+
+  // ---- layer-1 input into LDS (+ the batch staging for k_update: evaluation 0, part 0) ----
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int row = slab * ROWS + 16 * m + rr;
+    const bool st = N.stage && part == 0 && row < B;
 #pragma unroll
     for (int j = 0; j < NXV; ++j) {
       const int c = l16 + 16 * j;
       if (c < N.k1pad) {
-        const T tv = P::from_f32(c < N.in_dim ? xv[j] : 0.f);
-        xs[rr * K1P + c] = tv;
-        if (N.stage && c < N.in_dim) stg(reinterpret_cast<T *>(D.xT) + fidx<P>(c, row, D.BP / P::KM), tv);
+        const T tv = P::from_f32(c < N.in_dim ? xv[m][j] : 0.f);
+        xs[(16 * m + rr) * K1P + c] = tv;
+        if (st && c < N.in_dim) stg(reinterpret_cast<T *>(D.xT) + fidx<P>(c, row, D.BP / P::KM), tv);
       }
     }
-    if (N.stage) {
-      if (l16 < 2) stg(D.rd + (size_t)row * 2 + l16, rdv);
+    if (st) {
+      if (l16 < 2) stg(D.rd + (size_t)row * 2 + l16, rdv[m]);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        if (l16 + 16 * j < D.A) stg(D.actf + (size_t)row * D.A + l16 + 16 * j, av[j]);
+        if (l16 + 16 * j < D.A) stg(D.actf + (size_t)row * D.A + l16 + 16 * j, av[m][j]);
     }
-  };
-  mlp_slab<BF16, H>(N, D, &A, step, slab, smem, D.outs, D.OUTW, (int64_t)slab * SLAB, D.B, issue, fill);
+  }
+  __syncthreads();
+  STAMP(0, 2);
+
+  // ---- hidden layer 1: all H features (wave w: n-tiles w TPW .. +TPW), MT row tiles ----
+  {
+    f32x4 acc[MT][TPW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int jj = 0; jj < TPW; ++jj) acc[m][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < C::NK1; ++ks) {
+      if (ks < nk1) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const uint4 a = *reinterpret_cast<const uint4 *>(xs + (16 * m + r) * K1P + ks * P::KM + P::EPV * q);
+#pragma unroll
+          for (int jj = 0; jj < TPW; ++jj) P::mma(a, w1[ks][jj], acc[m][jj]);
+        }
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < TPW; ++jj) {
+      const int tile = wave * TPW + jj;
+      const int col = 16 * tile + r;
+      const float bias = P::round(bias1[jj]);
+      // the part that owns this tile's features stores them for the backward pass
+      const bool mine = N.train_slot >= 0 && (tile * SPL) / (4 * TPW) == part;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int row0 = slab * ROWS + 16 * m;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(P::round(acc[m][jj][i] + bias), 0.f);
+        if (N.dropout) {
+          bool keep[4];
+          dropout_keep4(D, A, step, 0, (row0 >> 2) + q, col, keep);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = keep[i] ? P::round(v[i] * D.drop_scale) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h1[(16 * m + 4 * q + i) * HP + col] = P::from_f32(v[i]);
+        if (mine && row0 < B)
+          store4T<BF16>(reinterpret_cast<T *>(D.hT) + (size_t)(N.train_slot * 2 + 0) * H * D.BP +
+                            fidx<P>(col, row0 + 4 * q, D.BP / P::KM), v);
+      }
+    }
+  }
+  __syncthreads();
+  STAMP(0, 3);
+
+  // ---- hidden layer 2: this part's 64 features, one n-tile per wave ----
+  {
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < C::NK2; ++ks) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(h1 + (16 * m + r) * HP + ks * P::KM + P::EPV * q);
+        P::mma(a, w2[ks], acc[m]);
+      }
+    }
+    const int col = 16 * tile2 + r;
+    const float bias = P::round(bias2);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int row0 = slab * ROWS + 16 * m;
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(P::round(acc[m][i] + bias), 0.f);
+      if (N.dropout) {
+        bool keep[4];
+        dropout_keep4(D, A, step, 1, (row0 >> 2) + q, col, keep);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = keep[i] ? P::round(v[i] * D.drop_scale) : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) h2[(16 * m + 4 * q + i) * HQP + 16 * wave + r] = P::from_f32(v[i]);
+      if (N.train_slot >= 0 && row0 < B)
+        store4T<BF16>(reinterpret_cast<T *>(D.hT) + (size_t)(N.train_slot * 2 + 1) * H * D.BP +
+                          fidx<P>(col, row0 + 4 * q, D.BP / P::KM), v);
+    }
+  }
+  __syncthreads();
+  STAMP(0, 4);
+
+  // ---- output layer, partial over this part's 64 hidden units: wave m < MT takes row tile m.
+  // No rounding here: the parts are summed in fp32 by the consumer, then rounded once.
+  if (wave < MT) {
+    const int m = wave;
+    f32x4 acc3[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < C::NK3; ++ks) {
+      const uint4 a = *reinterpret_cast<const uint4 *>(h2 + (16 * m + r) * HQP + ks * P::KM + P::EPV * q);
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+        if (jt < nt3) P::mma(a, w3[ks][jt], acc3[jt]);
+    }
+    float *outp = D.outs + (size_t)part * B * D.OUTW;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const int col = 16 * jt + r;
+      if (jt < nt3 && col < N.out_dim) {
+        const float bias = part == 0 ? P::round(bias3[jt]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = slab * ROWS + 16 * m + 4 * q + i;
+          if (row < B) stg(outp + (size_t)row * D.OUTW + N.out_col + col, acc3[jt][i] + bias);
+        }
+      }
+    }
+  }
+  STAMP(0, 5);
 }
 
 // ========================================================================
@@ -458,34 +649,39 @@ __global__ __launch_bounds__(256) void k_infer(const TrainerDesc *__restrict__ D
 // ------------------------------------------------------------------------
 // d(loss)/d(out) of output j of batch row b for network `net`, plus the logged
 // loss term and (Gaussian actor) the d(loss)/d(std) term  (ref:581-637).
-// Shared by k_backward and by the update tiles that rebuild dZ2 / dZ3 on the fly:
-// identical instruction sequence, identical bits.
 // ------------------------------------------------------------------------
 struct LossIn {
-  float qt[MAX_CRITICS];  // target critics (entries beyond E repeat the first); reduced in loss_terms,
-                          // so that nothing waits on these loads where they are issued
+  float qt[MAX_CRITICS];  // target critics (entries beyond E repeat the first); reduced in loss_terms
   float vv, mean, act, ls, nv, qv, rew, done;
 };
 
-// the loads of loss_terms, separated so that k_backward can issue them before its weight stream
-__device__ __forceinline__ LossIn loss_inputs(const TrainerDesc &D, int net, int b, int j) {
-  // Branch-free: every value any network could need is loaded from a clamped (always valid)
-  // address; loss_terms picks what applies.  Guarded loads would each become a branch followed
-  // by s_waitcnt vmcnt(0), i.e. one memory round trip per value.
-  const float *o = D.outs + (size_t)b * D.OUTW;
-  LossIn x;
-  // TwinQ.forward = min(q1, q2) of the target critics (ref:531-533, 583-584); min over all E
+// k_forward leaves every network output as SPL partial dot products (one per part of hidden
+// layer 2, the bias in part 0).  fin_loads requests the partials of one slab -- thread
+// (row tid / 16, lane16 = tid % 16) takes columns lane16 + 16 c of its row -- and fin_value adds
+// them in a fixed order, rounds the sum to the compute precision (the Linear's output dtype
+// under autocast) and applies the actor's tanh (ref:462-470).
+constexpr int FIN_NC = 4;   // column groups of 16: OUTW = 2E + 2 + A (rounded to 4) <= 52
+constexpr int FIN_LD = 64;  // LDS row stride of the finished outputs
+template <int SPL>
+__device__ __forceinline__ void fin_loads(const TrainerDesc &D, int b, int l16, float (&pv)[FIN_NC][SPL]) {
 #pragma unroll
-  for (int e = 0; e < MAX_CRITICS; ++e) x.qt[e] = ldg(o + D.out_qt + (e < D.E ? e : 0));
-  x.vv = ldg(o + D.out_v);
-  x.nv = ldg(o + D.out_nv);
-  x.qv = ldg(o + (net < D.E ? net : 0));
-  x.rew = ldg(D.rd + (size_t)b * 2), x.done = ldg(D.rd + (size_t)b * 2 + 1);
-  const int jc = j < D.A ? j : D.A - 1;
-  x.mean = ldg(o + D.out_mean + jc);
-  x.act = ldg(D.actf + (size_t)b * D.A + jc);
-  x.ls = ldg((D.deterministic ? D.actf : D.ls_snap) + jc);  // unused when deterministic
-  return x;
+  for (int c = 0; c < FIN_NC; ++c) {
+    const int col = l16 + 16 * c;
+    const int cc = col < D.OUTW ? col : D.OUTW - 1;  // branch-free: clamped, unused beyond OUTW
+#pragma unroll
+    for (int p = 0; p < SPL; ++p) pv[c][p] = ldg(D.outs + ((size_t)p * D.B + b) * D.OUTW + cc);
+  }
+}
+template <bool BF16, int SPL>
+__device__ __forceinline__ float fin_value(const TrainerDesc &D, const float (&pv)[SPL], int col) {
+  using P = Prec<BF16>;
+  float sum = pv[0];
+#pragma unroll
+  for (int p = 1; p < SPL; ++p) sum += pv[p];
+  float v = P::round(sum);
+  const bool is_mean = col >= D.out_mean && col < D.out_mean + D.A;
+  const float t = P::round(tanhf(v));
+  return is_mean ? t : v;
 }
 
 template <bool BF16>
@@ -541,46 +737,45 @@ __device__ __forceinline__ void loss_terms(const TrainerDesc &D, int net, const 
 
 // ========================================================================
 // k_backward
+//
+// One work-group = (trained net, 16-row slab, part of the dZ1 columns).  The W2^T stream is what
+// bounds this kernel (per-CU fetch rate from L2), so the H input features of layer 2 are split
+// into SPL parts of 64 (one 16-column tile per wave): every part redoes the cheap loss / dZ2
+// phase for all H hidden units (dZ2 is the GEMM's K operand) and streams H x 64 of W2^T.
+// The parts share the stores: part p writes its 64 columns of dZ2, part 0 writes dZ3 and the
+// loss partial sums.
 // ========================================================================
 template <bool BF16, int H>
 __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp, DevCtr *__restrict__ Cp,
                                               const int blk, char *smem, const int nslab, const int ntrain) {
   using K = KCfg<BF16, H>;
+  using C = FCfg<BF16, H>;
   using P = Prec<BF16>;
   using T = typename P::T;
-  // XCD slot x = blockIdx & 7 serves network x/2: each network's slabs sit on two XCDs.
-  // At H >= 128 two work-groups share a (net, slab): each streams HALF of W2^T (the per-CU
-  // fetch rate is what bounds this kernel) and produces half of the dZ1 columns; both redo
-  // the cheap loss / dZ2 phase, work-group 0 stores it.
-  constexpr int SPLIT = K::TPW >= 2 ? 2 : 1;
-  constexpr int TPH = K::TPW / SPLIT;  // n-tiles per wave in the dZ1 GEMM
-  // Job j = 2 net + sub lives on XCD j & 7, round j >> 3 (E = 2: XCD x serves network x / 2).
-  // SPLIT == 2: sub = which half of W2^T (each L2 fetches only the half its work-groups
-  // stream); SPLIT == 1: sub = slab parity.
-  // (nslab, ntrain: preloaded kernel arguments, see k_forward)
+  constexpr int SPL = C::SPL;
+  // Job j = SPL net + part lives on XCD j & 7, round j >> 3 (each L2 fetches only the part of
+  // W2^T its work-groups stream).  (nslab, ntrain: preloaded kernel arguments, see k_forward)
   const TrainerDesc &D = *Dp;
-  const int per_round = SPLIT == 2 ? nslab : (nslab + 1) / 2;
   const int idx_ = blk >> 3;
-  const int job = (idx_ / per_round) * 8 + (blk & 7), rest = idx_ % per_round;
-  const int net = job >> 1, sub = job & 1;
+  const int job = (idx_ / nslab) * 8 + (blk & 7), slab = idx_ % nslab;
+  const int net = job / SPL;
+  const int part = __builtin_amdgcn_readfirstlane(job % SPL);
   if (net >= ntrain) return;
-  const int half = SPLIT == 2 ? sub : 0;
-  const int slab = SPLIT == 2 ? rest : ((rest << 1) | sub);
-  if (slab >= nslab) return;
-  const int tile0 = half * (H / 16 / SPLIT) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * TPH;
   const TrainNet N = D.net[net];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-uniform branches stay scalar
+  const int tile0 = part * 4 + wave;  // this wave's n-tile of dZ1 (of H / 16)
   const int r = lane & 15, q = lane >> 4;
-  constexpr int HP = K::HP, TPW = K::TPW;
+  constexpr int HP = K::HP;
   const int B = D.B, BP = D.BP, nkb = D.BP / P::KM;
   const float fB = (float)B;
 
   T *dz2s = reinterpret_cast<T *>(smem);                       // [16][HP]
-  float *dz3 = reinterpret_cast<float *>(dz2s + SLAB * HP);    // [16][32] d(loss)/d(out)
-  float *lterm = dz3 + SLAB * 32;                              // [16][32] loss terms
-  float *gstd = lterm + SLAB * 32;                             // [16][32] d(loss)/d(std) terms
+  float *dz3 = reinterpret_cast<float *>(dz2s + SLAB * HP);    // [32][16] d(loss)/d(out), [j][row]
+  float *lterm = dz3 + SLAB * 32;                              // [32][16] loss terms
+  float *gstd = lterm + SLAB * 32;                             // [32][16] d(loss)/d(std) terms
   float *rowsum = gstd + SLAB * 32;                            // [16]
+  float *fin = rowsum + SLAB;                                  // [16][FIN_LD] finished forward outputs
 
   if (blk == 0 && tid == 0) Cp->ctr[1] = Cp->ctr[0] + 1;
   T *const g_dz1T = reinterpret_cast<T *>(D.dz1T), *const g_dz2T = reinterpret_cast<T *>(D.dz2T);
@@ -592,20 +787,29 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   const bool is_gauss_actor = net == D.net_a && !D.deterministic;
   pin_s(g_dz1T), pin_s(g_dz2T), pin_s(g_dz3T), pin_s(g_lsp), pin_s(g_lossp), pin_s(opmax), pin_s(n_act);
   pin_s(drop_scale), pin_s((int)drop_on), pin_s((int)is_gauss_actor);
+  pin_s(D.out_qt), pin_s(D.out_v), pin_s(D.out_nv), pin_s(D.out_mean), pin_s(D.E), pin_s(D.OUTW);
   STAMP(1, 0);
 
   // ---- the loss inputs first: loads return in order, these must not queue behind the
-  // weight stream requested next (thread e -> row e / out_dim, output e % out_dim) ----
-  // thread -> (row tid / 16, outputs tid % 16 and tid % 16 + 16): the per-row values are shared
-  // by both outputs, the second output only adds its mean / action / log_std (A <= 32)
+  // weight stream requested next.  Thread (row tid / 16, lane16 = tid % 16). ----
   const int lrow = tid >> 4, lj = tid & 15;
-  LossIn lin = loss_inputs(D, net, slab * SLAB + lrow, lj);
+  const int brow = slab * SLAB + lrow;
+  float pv[FIN_NC][SPL];
+  fin_loads<SPL>(D, brow, lj, pv);
+  const float rew = ldg(D.rd + (size_t)brow * 2), done = ldg(D.rd + (size_t)brow * 2 + 1);
+  float actv[2], lsv[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {  // outputs lj and lj + 16 (A <= 32); clamped, unused beyond A
+    const int jc = lj + 16 * h < D.A ? lj + 16 * h : D.A - 1;
+    actv[h] = ldg(D.actf + (size_t)brow * D.A + jc);
+    lsv[h] = ldg((D.deterministic ? D.actf : D.ls_snap) + jc);  // unused when deterministic
+  }
   // keep these loads AHEAD of the weight stream (the scheduler otherwise moves some of them
   // behind it, and loads return in order)
   __builtin_amdgcn_sched_barrier(0);
   // ---- request everything else that does not depend on the loss, in the order it is
-  // consumed (loads return in order): W3 and h2 for the dZ2 phase, then the W2^T stream for
-  // the GEMM, h1 for its epilogue.  All unconditional (clamped), see loss_inputs. ----
+  // consumed: W3 and h2 for the dZ2 phase, then this part of W2^T for the GEMM, h1 for its
+  // epilogue.  All unconditional (clamped). ----
   const T *W2T = reinterpret_cast<const T *>(N.w2ct);
   const T *W3c = reinterpret_cast<const T *>(N.wc[2]);
   const int c2 = tid < H ? tid : H - 1;  // hidden unit this thread owns in the dZ2 phase
@@ -620,33 +824,43 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
       load4T<BF16>(h2T + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), &h2v[4 * g4]);
   }
   __builtin_amdgcn_sched_barrier(0);
-  uint4 w2t[K::NKC][TPH];
-  load_w<P, K::NKC, TPH>(w2t, W2T, K::NK2, 0, K::NKC, tile0, lane);
-  float h1v[TPH][4];
+  uint4 w2t[K::NK2];
 #pragma unroll
-  for (int jj = 0; jj < TPH; ++jj)
-    load4T<BF16>(reinterpret_cast<const T *>(D.hT) + (size_t)(net * 2 + 0) * H * BP +
-                     fidx<P>(16 * (tile0 + jj) + r, slab * SLAB + 4 * q, nkb),
-                 h1v[jj]);
-
-  // ---- per-row loss terms and d(loss)/d(out)  (ref:581-637) ----
+  for (int ks = 0; ks < K::NK2; ++ks) w2t[ks] = ldg16(W2T + frag_off<P>(tile0, ks, K::NK2, lane));
+  float h1v[4];
+  load4T<BF16>(reinterpret_cast<const T *>(D.hT) + (size_t)(net * 2 + 0) * H * BP +
+                   fidx<P>(16 * tile0 + r, slab * SLAB + 4 * q, nkb),
+               h1v);
   STAMP(1, 1);
-  // LDS layout [j][16 rows]: the dZ2 phase reads four rows per instruction
-  {
-    float d3, lt, gs;
-    loss_terms<BF16>(D, net, lin, fB, d3, lt, gs);
-    if (lj < N.out_dim) dz3[lj * SLAB + lrow] = d3, lterm[lj * SLAB + lrow] = lt, gstd[lj * SLAB + lrow] = gs;
+
+  // ---- finish the forward outputs of this slab (sum of the parts, rounding, tanh) ----
+#pragma unroll
+  for (int c = 0; c < FIN_NC; ++c) {
+    const int col = lj + 16 * c;
+    if (col < D.OUTW) fin[lrow * FIN_LD + col] = fin_value<BF16, SPL>(D, pv[c], col);
   }
-  if (N.out_dim > 16) {
-    // outputs 16 .. A-1 (pen: A = 24): the second output of this thread's row reuses the row
-    // values and fetches its own mean / action / log_std here (one more round trip, actor only)
-    const int j = lj + 16, jc = j < D.A ? j : D.A - 1;
-    lin.mean = ldg(D.outs + (size_t)(slab * SLAB + lrow) * D.OUTW + D.out_mean + jc);
-    lin.act = ldg(D.actf + (size_t)(slab * SLAB + lrow) * D.A + jc);
-    lin.ls = ldg((D.deterministic ? D.actf : D.ls_snap) + jc);
-    float d3, lt, gs;
-    loss_terms<BF16>(D, net, lin, fB, d3, lt, gs);
-    if (j < N.out_dim) dz3[j * SLAB + lrow] = d3, lterm[j * SLAB + lrow] = lt, gstd[j * SLAB + lrow] = gs;
+  __syncthreads();
+
+  // ---- per-row loss terms and d(loss)/d(out)  (ref:581-637), LDS layout [j][16 rows] ----
+  {
+    const float *f = fin + lrow * FIN_LD;
+    LossIn lin;
+    // TwinQ.forward = min(q1, q2) of the target critics (ref:531-533, 583-584); min over all E
+#pragma unroll
+    for (int e = 0; e < MAX_CRITICS; ++e) lin.qt[e] = f[D.out_qt + (e < D.E ? e : 0)];
+    lin.vv = f[D.out_v], lin.nv = f[D.out_nv], lin.qv = f[net < D.E ? net : 0];
+    lin.rew = rew, lin.done = done;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = lj + 16 * h;
+      if (h == 0 || N.out_dim > 16) {
+        lin.mean = f[D.out_mean + (j < D.A ? j : D.A - 1)];
+        lin.act = actv[h], lin.ls = lsv[h];
+        float d3, lt, gs;
+        loss_terms<BF16>(D, net, lin, fB, d3, lt, gs);
+        if (j < N.out_dim) dz3[j * SLAB + lrow] = d3, lterm[j * SLAB + lrow] = lt, gstd[j * SLAB + lrow] = gs;
+      }
+    }
   }
   __syncthreads();
   STAMP(1, 2);
@@ -657,7 +871,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     for (int j = 0; j < N.out_dim; ++j) s += lterm[j * SLAB + tid];
     rowsum[tid] = s;
   }
-  if (half == 0 && is_gauss_actor && tid >= 64 && tid < 64 + n_act) {
+  if (part == 0 && is_gauss_actor && tid >= 64 && tid < 64 + n_act) {
     const int j = tid - 64;
     float s = 0.f;
 #pragma unroll
@@ -665,7 +879,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     stg(g_lsp + (size_t)slab * n_act + j, s);
   }
   // d(out), feature-major, for the layer-3 weight gradient
-  for (int e = tid; half == 0 && e < N.out_dim * SLAB; e += 256) {
+  for (int e = tid; part == 0 && e < N.out_dim * SLAB; e += 256) {
     const int j = e / SLAB, rr = e - j * SLAB;
     stg(g_dz3T + (size_t)net * opmax * BP + fidx<P>(j, slab * SLAB + rr, nkb),
         P::from_f32(dz3[j * SLAB + rr]));
@@ -688,6 +902,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
         }
       }
     }
+    const bool mine = c2 / C::HQ == part;  // the part that owns this hidden unit stores its dZ2
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       float outv[4];
@@ -699,42 +914,36 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
         outv[i] = h2v[rr] > 0.f ? sv : 0.f;
         dz2s[rr * HP + c2] = P::from_f32(outv[i]);
       }
-      if (half == 0) store4T<BF16>(dst + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), outv);
+      if (mine) store4T<BF16>(dst + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), outv);
     }
   }
   __syncthreads();
   STAMP(1, 3);
-  if (tid == 0 && half == 0) {
+  if (tid == 0 && part == 0) {
     float s = 0.f;
 #pragma unroll
     for (int rr = 0; rr < SLAB; ++rr) s += rowsum[rr];
     stg(g_lossp + net * nslab + slab, s);
   }
 
-  // ---- dZ1 = (dZ2 W2) * relu'(h1)   (MFMA, B operand = transposed copy) ----
+  // ---- dZ1 = (dZ2 W2) * relu'(h1)   (MFMA, B operand = transposed copy; one n-tile per wave) ----
   {
-    f32x4 acc[TPH];
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const T *xrow = dz2s + r * HP + P::EPV * q;
 #pragma unroll
-    for (int jj = 0; jj < TPH; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mma_w<P, K::NKC, TPH>(dz2s, HP, 0, K::NKC, w2t, acc, lane);
-#pragma unroll 1
-    for (int ch = 1; ch < K::NCH; ++ch) {
-      load_w<P, K::NKC, TPH>(w2t, W2T, K::NK2, ch * K::NKC, K::NKC, tile0, lane);
-      mma_w<P, K::NKC, TPH>(dz2s, HP, ch * K::NKC * P::KM, K::NKC, w2t, acc, lane);
+    for (int ks = 0; ks < K::NK2; ++ks) {
+      const uint4 a = *reinterpret_cast<const uint4 *>(xrow + ks * P::KM);
+      P::mma(a, w2t[ks], acc);
     }
+    const int col = 16 * tile0 + r;
+    float outv[4];
 #pragma unroll
-    for (int jj = 0; jj < TPH; ++jj) {
-      const int col = 16 * (tile0 + jj) + r;
-      float outv[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float s = P::round(acc[jj][i]);
-        if (drop_on) s = P::round(s * drop_scale);
-        outv[i] = h1v[jj][i] > 0.f ? s : 0.f;
-      }
-      store4T<BF16>(g_dz1T + (size_t)net * H * BP +
-                        fidx<P>(col, slab * SLAB + 4 * q, nkb), outv);
+    for (int i = 0; i < 4; ++i) {
+      float s = P::round(acc[i]);
+      if (drop_on) s = P::round(s * drop_scale);
+      outv[i] = h1v[i] > 0.f ? s : 0.f;
     }
+    store4T<BF16>(g_dz1T + (size_t)net * H * BP + fidx<P>(col, slab * SLAB + 4 * q, nkb), outv);
   }
   STAMP(1, 4);
 }
@@ -1334,14 +1543,24 @@ __global__ void k_sync_weights(const TrainerDesc *__restrict__ Dp) {
 // ------------------------------------------------------------------------
 // launchers (host driver: api.hip)
 // ------------------------------------------------------------------------
-size_t fwd_smem_bytes(bool bf16, int H, int k1max) {
+// k_infer (unsplit 16-row slabs, mlp_slab)
+size_t infer_smem_bytes(bool bf16, int H, int k1max) {
   const int es = bf16 ? 2 : 4, epv = bf16 ? 8 : 4;
   return (size_t)SLAB * (k1max + epv) * es + 2 * (size_t)SLAB * (H + epv) * es + 4 * 2 * 64 * 4 * 4;
 }
+// k_forward: xs [16 MT][k1max + EPV], h1 [16 MT][H + EPV], h2 [16 MT][64 + EPV]
+size_t fwd_smem_bytes(bool bf16, int H, int k1max, int mt) {
+  const int es = bf16 ? 2 : 4, epv = bf16 ? 8 : 4;
+  return (size_t)16 * mt * ((k1max + epv) + (H + epv) + (64 + epv)) * es;
+}
 size_t bwd_smem_bytes(bool bf16, int H) {
   const int es = bf16 ? 2 : 4, epv = bf16 ? 8 : 4;
-  return (size_t)SLAB * (H + epv) * es + 3 * SLAB * 32 * 4 + SLAB * 4;
+  return (size_t)SLAB * (H + epv) * es + 3 * SLAB * 32 * 4 + SLAB * 4 + SLAB * FIN_LD * 4;
 }
+// batch rows per forward work-group = 16 x this (more rows per work-group = fewer re-reads of
+// the weights; fewer work-groups): 2 for the headline batch 256 (224 work-groups at E = 2)
+int fwd_row_tiles(int B) { return (B % 64 == 0 && B >= 512) ? 4 : (B % 32 == 0 ? 2 : 1); }
+int layer2_parts(int H) { return H >= 256 ? 4 : H / 64; }
 
 #define DISPATCH_H(BF, HH, CALL)                 \
   do {                                           \
@@ -1358,17 +1577,26 @@ size_t bwd_smem_bytes(bool bf16, int H) {
 
 hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
                           const DevCtr *c, int n_seeds, hipStream_t st) {
-  const int grid = 8 * ((D.nfwd + 1 + 7) / 8) * (D.B / SLAB);  // nfwd evaluations + the spare job
-  const size_t sm = fwd_smem_bytes(bf16, D.H, D.k1max);
-#define CALL(BF, HH) \
-  hipLaunchKernelGGL((k_forward<BF, HH>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.nfwd)
+  const int mt = fwd_row_tiles(D.B), nsl = (D.B + 16 * mt - 1) / (16 * mt);
+  // nfwd evaluations + the spare job, each nsl slabs x SPL parts
+  const int grid = 8 * ((D.nfwd + 1 + 7) / 8) * nsl * layer2_parts(D.H);
+  const size_t sm = fwd_smem_bytes(bf16, D.H, D.k1max, mt);
+#define CALL(BF, HH)                                                                                          \
+  do {                                                                                                        \
+    if (mt == 4)                                                                                              \
+      hipLaunchKernelGGL((k_forward<BF, HH, 4>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsl, D.nfwd); \
+    else if (mt == 2)                                                                                         \
+      hipLaunchKernelGGL((k_forward<BF, HH, 2>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsl, D.nfwd); \
+    else                                                                                                      \
+      hipLaunchKernelGGL((k_forward<BF, HH, 1>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsl, D.nfwd); \
+  } while (0)
   DISPATCH_H(bf16, D.H, CALL);
 #undef CALL
   return hipGetLastError();
 }
 hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
                            DevCtr *c, int n_seeds, hipStream_t st) {
-  const int grid = 8 * ((2 * D.ntrain + 7) / 8) * (D.H >= 128 ? D.B / SLAB : (D.B / SLAB + 1) / 2);
+  const int grid = 8 * ((layer2_parts(D.H) * D.ntrain + 7) / 8) * (D.B / SLAB);
   const size_t sm = bwd_smem_bytes(bf16, D.H);
 #define CALL(BF, HH) \
   hipLaunchKernelGGL((k_backward<BF, HH>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain)
@@ -1391,7 +1619,7 @@ hipError_t launch_infer(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, 
                         const float *s, const float *a, int64_t n, float *out, int out_stride,
                         hipStream_t st) {
   const int grid = (int)((n + SLAB - 1) / SLAB);
-  const size_t sm = fwd_smem_bytes(bf16, D.H, D.k1max);
+  const size_t sm = infer_smem_bytes(bf16, D.H, D.k1max);
 #define CALL(BF, HH) \
   hipLaunchKernelGGL((k_infer<BF, HH>), dim3(grid), dim3(256), sm, st, dD, N, s, a, n, out, out_stride)
   DISPATCH_H(bf16, D.H, CALL);
