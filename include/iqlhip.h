@@ -83,6 +83,48 @@ int iqlhip_replay_pack(float *rows, int32_t row_stride, int32_t state_dim,
                        const float *obs, const float *act, const float *rew,
                        const float *next_obs, const float *done, void *stream);
 
+/* The same with the state z-scoring of ref:1438-1448 fused in: s and s' columns are written as
+ * (x - mean[c]) / std[c] (fp32, the arithmetic of normalize_states ref:138-139); mean / std are
+ * device fp32 [S] (iqlhip_prep_state_stats, or compute_mean_std results uploaded).            */
+int iqlhip_replay_pack_normalized(float *rows, int32_t row_stride, int32_t state_dim,
+                                  int32_t action_dim, int64_t first_row, int64_t n,
+                                  const float *obs, const float *act, const float *rew,
+                                  const float *next_obs, const float *done, const float *mean,
+                                  const float *std, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Dataset preparation on the device (the Python loops over the N transitions */
+/* that run before training starts).  All pointers are device pointers unless  */
+/* stated; terminals / timeouts are uint8 (0 / 1).                             */
+/* ------------------------------------------------------------------------ */
+/* ref:701-716 (= ref:938-951, 1127-1141, 1236-1253): keep[i] and the episode-step counter
+ * ep_steps[i] seen by transition i, for i < n - 1.  timeouts == NULL: `final` is
+ * (counter == max_episode_steps - 1) as in the reference.  Integer outputs: exact.          */
+int iqlhip_prep_keep_mask(const uint8_t *terminals, const uint8_t *timeouts, int64_t n,
+                          int32_t max_episode_steps, int32_t terminate_on_end, uint8_t *keep,
+                          int64_t *ep_steps, void *stream);
+/* ref:344-360 return_reward_range: an episode ends at a terminal or after max_episode_steps
+ * transitions.  *min_ret / *max_ret (HOST doubles) over the complete episodes -- every return
+ * is summed in double in transition order, so they equal the reference's bit for bit;
+ * trj_lens[i] (device double [n]) = length of the episode transition i belongs to.
+ * Synchronises `stream`.  IQLHIP_ERR_INVALID when no episode is complete.                   */
+int iqlhip_prep_reward_range(const float *rewards, const uint8_t *terminals, int64_t n,
+                             int32_t max_episode_steps, double *trj_lens, double *min_ret,
+                             double *max_ret, void *stream);
+/* ref:363-401 modify_reward, in place, with numpy's in-place float32 arithmetic:
+ *   sub_first 1: r -= min_ret (fp32)   2: r = fp32(double(r) - min_ret / trj_lens[i])
+ *   scale      : r /= fp32(max_ret - min_ret); r *= fp32(max_episode_steps)
+ *   sub_one    : r -= 1
+ * (which of them apply to which env / normalize_reward value is host logic).                */
+int iqlhip_prep_modify_reward(float *rewards, int64_t n, const double *trj_lens, int32_t sub_first,
+                              int32_t scale, int32_t sub_one, double min_ret, double max_ret,
+                              int32_t max_episode_steps, void *stream);
+/* ref:132-135 compute_mean_std: mean[c], std[c] + eps of obs[n][state_dim] (state_dim <= 256),
+ * accumulated in double in a fixed order (deterministic; differs from numpy's fp32 row-order
+ * sums at the 1e-6 level).                                                                  */
+int iqlhip_prep_state_stats(const float *obs, int64_t n, int32_t state_dim, double eps, float *mean,
+                            float *std, void *stream);
+
 /* ref:211-221 sample.  idx == NULL: indices are drawn on device,
  * idx[b] = philox4x32_10(key=seed, ctr=(b, step, stream 0)).x % n_rows
  * (oracle/philox.py); otherwise idx is a device int64[batch] that is used as

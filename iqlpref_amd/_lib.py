@@ -76,6 +76,14 @@ SYMBOLS = {
     "iqlhip_replay_row_stride": (C.c_int32, [C.c_int32, C.c_int32]),
     "iqlhip_replay_pack": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
                                      P, P, P, P, P, P]),
+    "iqlhip_replay_pack_normalized": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                                P, P, P, P, P, P, P, P]),
+    "iqlhip_prep_keep_mask": (C.c_int, [P, P, C.c_int64, C.c_int32, C.c_int32, P, P, P]),
+    "iqlhip_prep_reward_range": (C.c_int, [P, P, C.c_int64, C.c_int32, P, C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double), P]),
+    "iqlhip_prep_modify_reward": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                            C.c_double, C.c_int32, P]),
+    "iqlhip_prep_state_stats": (C.c_int, [P, C.c_int64, C.c_int32, C.c_double, P, P, P]),
     "iqlhip_replay_sample": (C.c_int, [C.POINTER(ReplayView), C.c_int32, P, C.c_uint64,
                                        C.c_uint64, P, P, P, P, P, P, P]),
     "iqlhip_arena_layout": (C.c_int, [C.POINTER(TrainerConfig), C.POINTER(C.c_int64 * N_TENSORS),

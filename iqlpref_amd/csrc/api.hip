@@ -37,6 +37,17 @@ hipError_t launch_sample(const iqlhip_replay_view &v, int batch, const int64_t *
 hipError_t launch_mlp_f32(const iqlhip_mlp_desc &d, const float *x, int64_t n, int x_stride, float *out,
                           int out_stride, hipStream_t st);
 hipError_t launch_cvar(const float *preds, int S, int64_t N, int n_tail, float *out, hipStream_t st);
+hipError_t launch_keep_steps(const uint8_t *term, const uint8_t *tmo, int64_t n, int64_t M, int toe,
+                             uint8_t *keep, int64_t *ep_steps, hipStream_t st);
+hipError_t launch_reward_range(const float *rew, const uint8_t *term, int64_t n, int64_t M, double *trj_lens,
+                               double *out3, hipStream_t st);
+hipError_t launch_modify_reward(float *rew, int64_t n, const double *trj_lens, int sub_first, int scale,
+                                int sub_one, double min_ret, double range, float steps, hipStream_t st);
+hipError_t launch_state_stats(const float *x, int64_t n, int S, double eps, float *mean_f, float *std_f,
+                              hipStream_t st);
+hipError_t launch_pack_norm(float *rows, int stride, int S, int A, int64_t first, int64_t n, const float *obs,
+                            const float *act, const float *rew, const float *nxt, const float *done,
+                            const float *mean, const float *sd, hipStream_t st);
 size_t pt_smem_bytes(const iqlhip_pt_weights &W, int ql);
 hipError_t launch_pt(const iqlhip_pt_weights &W, const float *obs, const float *act, int64_t n_rows,
                      const int64_t *win_start, const int32_t *win_len, int64_t n_win, int ql, float *out,
@@ -84,6 +95,64 @@ extern "C" int iqlhip_replay_pack(float *rows, int32_t row_stride, int32_t S, in
   if (n == 0) return 0;
   HIP_TRY(launch_pack(rows, row_stride, S, A, first_row, n, obs, act, rew, next_obs, done,
                       (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int iqlhip_replay_pack_normalized(float *rows, int32_t row_stride, int32_t S, int32_t A,
+                                             int64_t first_row, int64_t n, const float *obs, const float *act,
+                                             const float *rew, const float *next_obs, const float *done,
+                                             const float *mean, const float *std, void *stream) {
+  if (!rows || !obs || !act || !rew || !next_obs || !done || !mean || !std)
+    return fail(IQLHIP_ERR_INVALID, "null pointer");
+  if (S <= 0 || A <= 0 || n < 0 || first_row < 0 || row_stride < 2 * S + A + 2 || (row_stride & 3))
+    return fail(IQLHIP_ERR_INVALID, "bad replay geometry S=%d A=%d stride=%d", S, A, row_stride);
+  if (n == 0) return 0;
+  HIP_TRY(launch_pack_norm(rows, row_stride, S, A, first_row, n, obs, act, rew, next_obs, done, mean, std,
+                           (hipStream_t)stream));
+  return 0;
+}
+
+// ------------------------------------------------------- dataset preparation --
+extern "C" int iqlhip_prep_keep_mask(const uint8_t *terminals, const uint8_t *timeouts, int64_t n,
+                                     int32_t max_episode_steps, int32_t terminate_on_end, uint8_t *keep,
+                                     int64_t *ep_steps, void *stream) {
+  if (!terminals || !keep || !ep_steps) return fail(IQLHIP_ERR_INVALID, "null pointer");
+  if (n < 1) return fail(IQLHIP_ERR_INVALID, "n must be >= 1");
+  if (!timeouts && max_episode_steps < 1) return fail(IQLHIP_ERR_INVALID, "max_episode_steps must be >= 1");
+  HIP_TRY(launch_keep_steps(terminals, timeouts, n, max_episode_steps, terminate_on_end != 0, keep, ep_steps,
+                            (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int iqlhip_prep_reward_range(const float *rewards, const uint8_t *terminals, int64_t n,
+                                        int32_t max_episode_steps, double *trj_lens, double *min_ret,
+                                        double *max_ret, void *stream) {
+  if (!rewards || !terminals || !trj_lens || !min_ret || !max_ret) return fail(IQLHIP_ERR_INVALID, "null pointer");
+  if (n < 1 || max_episode_steps < 1) return fail(IQLHIP_ERR_INVALID, "n and max_episode_steps must be >= 1");
+  double out3[3];
+  HIP_TRY(launch_reward_range(rewards, terminals, n, max_episode_steps, trj_lens, out3, (hipStream_t)stream));
+  if (out3[2] == 0.0) return fail(IQLHIP_ERR_INVALID, "dataset holds no complete episode");
+  *min_ret = out3[0], *max_ret = out3[1];
+  return 0;
+}
+
+extern "C" int iqlhip_prep_modify_reward(float *rewards, int64_t n, const double *trj_lens, int32_t sub_first,
+                                         int32_t scale, int32_t sub_one, double min_ret, double max_ret,
+                                         int32_t max_episode_steps, void *stream) {
+  if (!rewards) return fail(IQLHIP_ERR_INVALID, "null pointer");
+  if (sub_first < 0 || sub_first > 2) return fail(IQLHIP_ERR_INVALID, "sub_first must be 0, 1 or 2");
+  if (sub_first == 2 && !trj_lens) return fail(IQLHIP_ERR_INVALID, "sub_first = 2 needs trj_lens");
+  if (n <= 0) return 0;
+  HIP_TRY(launch_modify_reward(rewards, n, trj_lens, sub_first, scale != 0, sub_one != 0, min_ret,
+                               max_ret - min_ret, (float)max_episode_steps, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int iqlhip_prep_state_stats(const float *obs, int64_t n, int32_t state_dim, double eps, float *mean,
+                                       float *std, void *stream) {
+  if (!obs || !mean || !std) return fail(IQLHIP_ERR_INVALID, "null pointer");
+  if (n < 1 || state_dim < 1 || state_dim > 256) return fail(IQLHIP_ERR_UNSUPPORTED, "n >= 1, 1 <= state_dim <= 256");
+  HIP_TRY(launch_state_stats(obs, n, state_dim, eps, mean, std, (hipStream_t)stream));
   return 0;
 }
 

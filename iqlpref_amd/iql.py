@@ -191,22 +191,39 @@ class ReplayBuffer:
         return torch.tensor(data, dtype=torch.float32, device=self._dev)
 
     def load_d4rl_dataset(self, data: Dict[str, np.ndarray]):
+        """ref:193-209: the five arrays are uploaded once and interleaved on the device."""
+        self.load_device_arrays(
+            self._to_tensor(data["observations"]), self._to_tensor(data["actions"]),
+            self._to_tensor(data["rewards"]), self._to_tensor(data["next_observations"]),
+            self._to_tensor(data["terminals"]))
+
+    def load_device_arrays(self, obs: torch.Tensor, act: torch.Tensor, rew: torch.Tensor, nxt: torch.Tensor,
+                           done: torch.Tensor, state_mean: Optional[torch.Tensor] = None,
+                           state_std: Optional[torch.Tensor] = None):
+        """``load_d4rl_dataset`` for arrays that already live on the device (iqlpref_amd.prep).
+        With ``state_mean`` / ``state_std`` ([S] float32 device tensors) the z-scoring of
+        ref:1438-1448 is fused into the interleave: s and s' are stored as (x - mean) / std."""
         if self._size != 0:
             raise ValueError("Trying to load data into non-empty replay buffer")
-        n = data["observations"].shape[0]
+        n = obs.shape[0]
         if n > self._buffer_size:
             raise ValueError("Replay buffer is smaller than the dataset you are trying to load!")
+        f = lambda t, shape: t.to(device=self._dev, dtype=torch.float32).reshape(shape).contiguous()
+        S, A = self._state_dim, self._action_dim
+        obs, act, nxt = f(obs, (n, S)), f(act, (n, A)), f(nxt, (n, S))
+        rew, done = f(rew, (n,)), f(done, (n,))
         self._alloc(n)
-        obs = self._to_tensor(data["observations"]).contiguous()
-        act = self._to_tensor(data["actions"]).contiguous()
-        rew = self._to_tensor(data["rewards"]).reshape(-1).contiguous()
-        nxt = self._to_tensor(data["next_observations"]).contiguous()
-        done = self._to_tensor(data["terminals"]).reshape(-1).contiguous()
         with torch.cuda.device(self._dev):
-            check(self._lib.iqlhip_replay_pack(
-                ptr(self._rows), self._stride, self._state_dim, self._action_dim, 0, n,
-                ptr(obs), ptr(act), ptr(rew), ptr(nxt), ptr(done), stream_ptr()))
-        torch.cuda.current_stream(self._dev).synchronize()  # the five staging tensors die here
+            if state_mean is None:
+                check(self._lib.iqlhip_replay_pack(
+                    ptr(self._rows), self._stride, S, A, 0, n,
+                    ptr(obs), ptr(act), ptr(rew), ptr(nxt), ptr(done), stream_ptr()))
+            else:
+                mean, std = f(state_mean, (S,)), f(state_std, (S,))
+                check(self._lib.iqlhip_replay_pack_normalized(
+                    ptr(self._rows), self._stride, S, A, 0, n,
+                    ptr(obs), ptr(act), ptr(rew), ptr(nxt), ptr(done), ptr(mean), ptr(std), stream_ptr()))
+        torch.cuda.current_stream(self._dev).synchronize()  # the staging tensors die here
         self._size += n
         self._pointer = min(self._size, n)
         print(f"Dataset size: {n}")

@@ -26,12 +26,20 @@ from .iql import mlp_forward_f32
 # --------------------------------------------------------------------------- #
 # keep mask / episode step  (ref:701-716, ref:1236-1253)
 # --------------------------------------------------------------------------- #
-def keep_mask_and_steps(terminals, timeouts, max_episode_steps: int, terminate_on_end: bool = False):
-    """Vectorised form of the reference's single pass over N-1 transitions.
+def keep_mask_and_steps(terminals, timeouts, max_episode_steps: int, terminate_on_end: bool = False,
+                        device=None):
+    """Vectorised form of the reference's single pass over N-1 transitions.  With ``device``
+    (a ROCm device) the scan runs in the kernels of csrc/prep.hip and the two arrays are
+    copied back; the host form below is the same computation in numpy.
 
     Returns (keep[N-1] bool, ep_steps[N-1] int64).  The episode-step counter is 0
     after a dropped (final, not terminate_on_end) transition and 1 after a kept
     terminal / final one -- the D4RL quirk the reference inherits (ref:713-716)."""
+    if device is not None:
+        from . import prep
+        keep_t, steps_t = prep.keep_mask_and_steps(terminals, timeouts, max_episode_steps, terminate_on_end,
+                                                   device)
+        return keep_t.cpu().numpy(), steps_t.cpu().numpy()
     term = np.asarray(terminals).reshape(-1).astype(bool)[:-1]
     n = term.shape[0]
     if timeouts is not None:
@@ -343,11 +351,11 @@ def _device_of(model):
 def qlearning_dataset_mr(env, r_model, dataset=None, terminate_on_end=False, **kwargs):
     """ref:691-732: one reward-MLP forward over all N-1 transitions, on device."""
     dataset, obs_all, act_all = _dataset_arrays(env, dataset, kwargs)
-    keep, _ = keep_mask_and_steps(dataset["terminals"], dataset.get("timeouts"), _max_steps(env),
-                                  terminate_on_end)
     if not isinstance(r_model, RewardMLP):
         raise TypeError("r_model must be an iqlpref_amd RewardMLP (load_mlp_reward_model)")
     device = _device_of(r_model)
+    keep, _ = keep_mask_and_steps(dataset["terminals"], dataset.get("timeouts"), _max_steps(env),
+                                  terminate_on_end, device=device)
     obs_act = torch.from_numpy(np.concatenate([obs_all[:-1], act_all[:-1]], axis=1)).to(device)
     all_rewards = r_model(obs_act).squeeze(-1).cpu().numpy()
     return _finish(dataset, obs_all, act_all, all_rewards, keep)
@@ -413,7 +421,7 @@ def qlearning_dataset_mr_ensemble(env, reward_model_dir: str, alpha: float = 0.9
     dev = _lib.require_gpu(device)
     dataset, obs_all, act_all = _dataset_arrays(env, dataset, kwargs)
     keep, _ = keep_mask_and_steps(dataset["terminals"], dataset.get("timeouts"), _max_steps(env),
-                                  terminate_on_end)
+                                  terminate_on_end, device=dev)
     ckpt_paths = _discover_mr_snapshots(reward_model_dir, burn_in)
     n_total = len(ckpt_paths)
     n_tail = _tail_count(alpha, n_total)
@@ -443,7 +451,7 @@ def qlearning_dataset_bnn(env, reward_model_dir: str, alpha: float = 0.95, n_sam
     dev = _lib.require_gpu(device)
     dataset, obs_all, act_all = _dataset_arrays(env, dataset, kwargs)
     keep, _ = keep_mask_and_steps(dataset["terminals"], dataset.get("timeouts"), _max_steps(env),
-                                  terminate_on_end)
+                                  terminate_on_end, device=dev)
     sampling_dir = os.path.join(reward_model_dir, "sampling_f")
     weight_files = sorted(_glob.glob(os.path.join(
         sampling_dir, "chain_*/sampled_weights/sampled_weights_0000000")))
@@ -627,11 +635,11 @@ def qlearning_dataset_pt(env, r_model, query_length=100, dataset=None, terminate
     evaluated and scattered.  ``correct_window_offsets=True`` evaluates the window
     that ends at each transition instead (one per transition)."""
     dataset, obs_all, act_all = _dataset_arrays(env, dataset, kwargs)
-    keep, ep_steps = keep_mask_and_steps(dataset["terminals"], dataset.get("timeouts"), _max_steps(env),
-                                         terminate_on_end)
     if not isinstance(r_model, RewardPT):
         raise TypeError("r_model must be an iqlpref_amd RewardPT (load_pt_reward_model)")
     dev = _device_of(r_model)
+    keep, ep_steps = keep_mask_and_steps(dataset["terminals"], dataset.get("timeouts"), _max_steps(env),
+                                         terminate_on_end, device=dev)
     n = ep_steps.shape[0]
     lens = np.minimum(ep_steps + 1, query_length)
     if correct_window_offsets:

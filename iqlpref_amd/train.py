@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import distributed as D
+from . import prep
 from .iql import (DeterministicPolicy, EnsembleQ, GaussianPolicy, ImplicitQLearning, ReplayBuffer, TrainConfig, TwinQ,
                   ValueFunction, compute_mean_std, normalize_states, set_seed)
 from .relabel import (load_mlp_reward_model, load_pt_reward_model, modify_reward, qlearning_dataset_bnn,
@@ -156,11 +157,13 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
           action_dim: Optional[int] = None, max_action: Optional[float] = None,
           logger: Optional[Callable[[Dict[str, float], int], None]] = None,
           evaluate: Optional[Callable] = None, precision: str = "bf16",
-          raw_dataset=None) -> ImplicitQLearning:
+          raw_dataset=None, host_prep: bool = False) -> ImplicitQLearning:
     """ref:1393-1570.  ``dataset``: an already-built qlearning dataset (skips d4rl);
     ``raw_dataset``: an env.get_dataset()-style dict handed to the relabel functions;
     ``evaluate(actor, step) -> (scores, steps_to_goal)`` replaces eval_actor when gym is
-    not installed (None: evaluation is skipped)."""
+    not installed (None: evaluation is skipped); ``host_prep``: run the dataset preparation of
+    ref:1435-1456 in numpy on the host (the reference's arithmetic to the last bit) instead of the
+    device kernels of iqlpref_amd.prep (state statistics agree to ~1e-6, everything else exactly)."""
     # one process per GPU: under torchrun this rank owns cuda:<LOCAL_RANK>, and everything
     # below (process group, buffer, trainer, metric all-gather) lives there
     bound = D.local_device()
@@ -176,16 +179,21 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
     dataset = build_dataset(config, env, dataset if dataset is not None else raw_dataset) \
         if (config.reward_model_path or dataset is None) else dataset
 
-    if config.normalize_reward:
-        modify_reward(dataset, config.env, config.normalize_reward)
-    if config.normalize:
-        state_mean, state_std = compute_mean_std(dataset["observations"], eps=1e-3)
-    else:
-        state_mean, state_std = 0, 1
-    dataset["observations"] = normalize_states(dataset["observations"], state_mean, state_std)
-    dataset["next_observations"] = normalize_states(dataset["next_observations"], state_mean, state_std)
     replay_buffer = ReplayBuffer(state_dim, action_dim, config.buffer_size, config.device)
-    replay_buffer.load_d4rl_dataset(dataset)
+    if host_prep:  # ref:1435-1456 as written: numpy on the host, then one upload
+        if config.normalize_reward:
+            modify_reward(dataset, config.env, config.normalize_reward)
+        if config.normalize:
+            state_mean, state_std = compute_mean_std(dataset["observations"], eps=1e-3)
+        else:
+            state_mean, state_std = 0, 1
+        dataset["observations"] = normalize_states(dataset["observations"], state_mean, state_std)
+        dataset["next_observations"] = normalize_states(dataset["next_observations"], state_mean, state_std)
+        replay_buffer.load_d4rl_dataset(dataset)
+    else:  # the same on the device: one upload, the z-scoring fused into the buffer load
+        state_mean, state_std = prep.prepare_replay(
+            dataset, replay_buffer, env_name=config.env, normalize_reward=config.normalize_reward,
+            normalize=config.normalize, eps=1e-3)
     if max_action is None:
         max_action = float(env.action_space.high[0])
 
