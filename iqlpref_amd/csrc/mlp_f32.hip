@@ -3,38 +3,71 @@
 // containers outside the autocast region (ref:452-543, eval_actor ref:306-319)
 // and the Markovian reward relabel (ref:719-724, ref:986-991, ref:1176-1178).
 //
-// One work-group = 64 rows: four 16-row M tiles share every weight fragment, so
-// the weights (L2 resident) are read once per 64 rows; activations ping-pong
-// between two LDS buffers and never touch HBM.  Weights are read from the fp32
-// masters in either layout ([out][in] torch Linear, or [in][out] x@W).
+// Two launches per call:
+//   k_mlp_repack  every layer's weights (torch [out][in] or x@W [in][out]) are rewritten once
+//                 into the fragment-major image of common.h (zero padded to 16 x 16): a B
+//                 fragment is then ONE contiguous 1 KiB read per wave instruction instead of
+//                 64 scalar loads with stride K between lanes.
+//   k_mlp_f32     one work-group = 64 rows.  The activations live in ONE LDS buffer
+//                 [64][lda] (67 KB at width 256: two work-groups per CU); a layer is computed
+//                 into registers (wave w owns n-tiles w, w+4, w+8, w+12; four 16-row M tiles
+//                 share every B fragment; A fragments are shared by the wave's four n-tiles),
+//                 then written back in place behind a barrier.  Per 16-deep k-step a wave issues
+//                 4 LDS reads, 4 fragment loads (the next step's, prefetched) and 64 MFMAs.
 #include "../../include/iqlhip.h"
 #include "common.h"
 
 namespace iqlhip {
 
 constexpr int MROWS = 64;
+constexpr int MAXT = 4;  // n-tiles per wave: widths <= 256
 
 struct MlpArgs {
   int32_t n_layers;
   int32_t dims[IQLHIP_MLP_MAX_LAYERS + 1];
-  const float *W[IQLHIP_MLP_MAX_LAYERS];
+  const float *Wf[IQLHIP_MLP_MAX_LAYERS];  // fragment-major [round16(out)][round16(in)]
   const float *b[IQLHIP_MLP_MAX_LAYERS];
-  int32_t w_in_out;    // 1: W is [in][out]
   int32_t hidden_act;  // 0 relu, 1 tanh
   int32_t out_act;     // 0 none, 1 tanh
   int32_t lda;         // LDS row stride (floats)
 };
 
+struct RepackArgs {
+  int32_t n_layers;
+  int32_t dims[IQLHIP_MLP_MAX_LAYERS + 1];
+  const float *W[IQLHIP_MLP_MAX_LAYERS];
+  float *Wf[IQLHIP_MLP_MAX_LAYERS];
+  int32_t w_in_out;  // 1: W is [in][out]
+};
+
+__global__ void k_mlp_repack(const RepackArgs R) {
+  using P = Prec<false>;
+  const int l = blockIdx.y;
+  if (l >= R.n_layers) return;
+  const int K = R.dims[l], N = R.dims[l + 1];
+  const int Kp = round_up(K, 16), Np = round_up(N, 16);
+  const float *W = R.W[l];
+  float *Wf = R.Wf[l];
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < Np * Kp; e += gridDim.x * blockDim.x) {
+    // consecutive threads read consecutive source elements of the layout at hand
+    const int f = R.w_in_out ? e % Np : e / Kp, k = R.w_in_out ? e / Np : e % Kp;
+    float v = 0.f;
+    if (f < N && k < K) v = R.w_in_out ? W[(size_t)k * N + f] : W[(size_t)f * K + k];
+    Wf[fidx<P>(f, k, Kp / 16)] = v;
+  }
+}
+
 __device__ __forceinline__ float act_apply(float v, int kind) {
   return kind == 0 ? fmaxf(v, 0.f) : tanhf(v);
 }
 
-__global__ __launch_bounds__(256) void k_mlp_f32(const MlpArgs M, const float *__restrict__ x, int64_t n,
-                                                 int x_stride, float *__restrict__ out, int out_stride) {
+__global__ __launch_bounds__(256, 2) void k_mlp_f32(const MlpArgs M, const float *__restrict__ x, int64_t n,
+                                                    int x_stride, float *__restrict__ out, int out_stride) {
+  using P = Prec<false>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float *buf0 = reinterpret_cast<float *>(smem);
-  float *buf1 = buf0 + MROWS * M.lda;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float *buf = reinterpret_cast<float *>(smem);  // [MROWS][lda]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * MROWS;
   const int lda = M.lda;
@@ -45,89 +78,120 @@ __global__ __launch_bounds__(256) void k_mlp_f32(const MlpArgs M, const float *_
     for (int e = tid; e < MROWS * K0p; e += 256) {
       const int rr = e / K0p, c = e - rr * K0p;
       float v = 0.f;
-      if (row0 + rr < n && c < K0) v = x[(size_t)(row0 + rr) * x_stride + c];
-      buf0[rr * lda + c] = v;
+      if (row0 + rr < n && c < K0) v = ldg(x + (size_t)(row0 + rr) * x_stride + c);
+      buf[rr * lda + c] = v;
     }
   }
   __syncthreads();
 
-  float *in = buf0, *ob = buf1;
   for (int l = 0; l < M.n_layers; ++l) {
     const int K = M.dims[l], N = M.dims[l + 1];
-    const int Kp = round_up(K, 16), ntile = (N + 15) / 16;
-    const float *W = M.W[l];
+    const int nk = round_up(K, 16) / 16, ntile = round_up(N, 16) / 16;
+    const float *Wf = M.Wf[l];
     const float *bias = M.b[l];
     const bool last = l == M.n_layers - 1;
-    for (int jt = wave; jt < ntile; jt += 4) {
-      f32x4 acc[4];
+    // this wave's n-tiles: wave, wave + 4, ... (clamped copies beyond ntile are computed on a
+    // valid fragment and dropped: no branches in the load stream)
+    int tile[MAXT];
+    bool live[MAXT];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int ncol = 16 * jt + r;
-      for (int kb = 0; kb < Kp; kb += 16) {
-        float bw[4];
+    for (int t = 0; t < MAXT; ++t) {
+      live[t] = wave + 4 * t < ntile;
+      tile[t] = live[t] ? wave + 4 * t : 0;
+    }
+    f32x4 acc[MAXT][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int k = kb + 4 * q + c;
-          bw[c] = (k < K && ncol < N)
-                      ? (M.w_in_out ? W[(size_t)k * N + ncol] : W[(size_t)ncol * K + k])
-                      : 0.f;
+    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bv[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) bv[t] = ldg(bias + (16 * tile[t] + r < N ? 16 * tile[t] + r : N - 1));
+    if (live[0]) {  // wave-uniform: a wave without tiles (narrow layers) skips the k loop
+      uint4 bq[MAXT];
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) bq[t] = ldg16(Wf + frag_off<P>(tile[t], 0, nk, lane));
+      for (int ks = 0; ks < nk; ++ks) {
+        uint4 bn[MAXT];  // next k-step's fragments, in flight during this step's MFMAs
+        const int kn = ks + 1 < nk ? ks + 1 : ks;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) bn[t] = ldg16(Wf + frag_off<P>(tile[t], kn, nk, lane));
+        uint4 a[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          a[m] = *reinterpret_cast<const uint4 *>(buf + (16 * m + r) * lda + 16 * ks + 4 * q);
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+          if (live[t]) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) P::mma(a[m], bq[t], acc[t][m]);
+          }
         }
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const float4 a = *reinterpret_cast<const float4 *>(in + (16 * m + r) * lda + kb + 4 * q);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw[0], acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw[1], acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw[2], acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bw[3], acc[m], 0, 0, 0);
-        }
+        for (int t = 0; t < MAXT; ++t) bq[t] = bn[t];
       }
-      const float bv = ncol < N ? bias[ncol] : 0.f;
+    }
+    __syncthreads();  // every wave has read its last A fragment: the buffer may be overwritten
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      if (!live[t]) continue;
+      const int ncol = 16 * tile[t] + r;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int rr = 16 * m + 4 * q + i;
-          float v = acc[m][i] + bv;
+          float v = acc[t][m][i] + bv[t];
           if (!last) {
-            v = ncol < N ? act_apply(v, M.hidden_act) : 0.f;
-            ob[rr * lda + ncol] = v;
+            buf[rr * lda + ncol] = ncol < N ? act_apply(v, M.hidden_act) : 0.f;  // zero K padding
           } else if (ncol < N && row0 + rr < n) {
             if (M.out_act == 1) v = tanhf(v);
-            out[(size_t)(row0 + rr) * out_stride + ncol] = v;
+            stg(out + (size_t)(row0 + rr) * out_stride + ncol, v);
           }
         }
       }
     }
     __syncthreads();
-    float *t = in;
-    in = ob, ob = t;
   }
 }
 
 hipError_t launch_mlp_f32(const iqlhip_mlp_desc &d, const float *x, int64_t n, int x_stride, float *out,
                           int out_stride, hipStream_t st) {
   MlpArgs M;
-  M.n_layers = d.n_layers;
+  RepackArgs R;
+  M.n_layers = R.n_layers = d.n_layers;
   int maxd = 0;
+  size_t total = 0, off[IQLHIP_MLP_MAX_LAYERS];
   for (int i = 0; i <= d.n_layers; ++i) {
-    M.dims[i] = d.dims[i];
-    if (i < d.n_layers && d.dims[i] > maxd) maxd = d.dims[i];
-    if (i > 0 && i < d.n_layers && d.dims[i] > maxd) maxd = d.dims[i];
+    M.dims[i] = R.dims[i] = d.dims[i];
+    if (i < d.n_layers && d.dims[i] > maxd) maxd = d.dims[i];  // widths that pass through the LDS buffer
   }
-  for (int i = 0; i < d.n_layers; ++i) M.W[i] = d.weights[i], M.b[i] = d.biases[i];
-  M.w_in_out = d.w_in_out, M.hidden_act = d.hidden_act, M.out_act = d.out_act;
+  for (int i = 0; i < d.n_layers; ++i) {
+    off[i] = total;
+    total += (size_t)round_up(d.dims[i], 16) * round_up(d.dims[i + 1], 16);
+  }
+  float *wf = nullptr;  // stream-ordered scratch for the fragment-major images (<= 8 x 256 KB)
+  hipError_t e = hipMallocAsync((void **)&wf, total * sizeof(float), st);
+  if (e != hipSuccess) return e;
+  for (int i = 0; i < d.n_layers; ++i) {
+    R.W[i] = d.weights[i], R.Wf[i] = wf + off[i];
+    M.Wf[i] = wf + off[i], M.b[i] = d.biases[i];
+  }
+  R.w_in_out = d.w_in_out;
+  M.hidden_act = d.hidden_act, M.out_act = d.out_act;
   M.lda = round_up(maxd, 16) + 4;
-  const size_t sm = (size_t)2 * MROWS * M.lda * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_f32),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
+  hipLaunchKernelGGL(k_mlp_repack, dim3(64, d.n_layers), dim3(256), 0, st, R);
+  const size_t sm = (size_t)MROWS * M.lda * sizeof(float);
+  // (set on every call: the attribute is per device, and a process may drive several)
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_f32), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          160 * 1024);
+  if (e == hipSuccess) {
+    const int64_t grid = (n + MROWS - 1) / MROWS;
+    hipLaunchKernelGGL(k_mlp_f32, dim3((unsigned)grid), dim3(256), sm, st, M, x, n, x_stride, out, out_stride);
+    e = hipGetLastError();
   }
-  const int64_t grid = (n + MROWS - 1) / MROWS;
-  hipLaunchKernelGGL(k_mlp_f32, dim3((unsigned)grid), dim3(256), sm, st, M, x, n, x_stride, out, out_stride);
-  return hipGetLastError();
+  (void)hipFreeAsync(wf, st);
+  return e;
 }
 
 }  // namespace iqlhip

@@ -1,24 +1,33 @@
 // Preference-transformer reward relabel (ref:1223-1309 qlearning_dataset_pt;
 // architecture reward_models/pref_transformer.py:170-277, reward_models/ops.py:6-117).
 //
-// One work-group walks a queue of windows.  A window is `len` consecutive
-// transitions (len <= query_length; left padding of the reference's batch is
-// never materialised: padded keys get -1e4 and vanish from the fp32 softmax).
-// The reference only reads value[:, 0, -1, 0], so for the (single) GPT-2 block
-// only the LAST action token needs a query, attention output and MLP; every
-// token still needs its key and value.
+// One work-group (8 waves) walks a queue of windows.  A window is `len` consecutive
+// transitions (len <= query_length; left padding of the reference's batch is never
+// materialised: padded keys get -1e4 and vanish from the fp32 softmax).  The reference only
+// reads value[:, 0, -1, 0], so for the (single) GPT-2 block only the LAST action token needs a
+// query, attention output and MLP; every token still needs its key and value.
 //
-// embd_dim == 64 == wave size: lane e of a wave owns embedding element e of the
-// token that wave is processing, LayerNorm statistics are wave reductions, a
-// lane keeps ITS row of Wk and Wv (128 VGPRs) for the whole kernel, keys (bf16,
-// as ops.py:74-76 casts them) and values live in LDS.  fp32 arithmetic except
-// the q.k products, which follow the reference's bf16 cast.
+// The per-token work is the two batched Linear layers of the model and runs on the exact-fp32
+// matrix cores (v_mfma_f32_16x16x4_f32), 16 tokens of one kind (state / action) per wave job:
+//   embedding   [16 x S|A] . W^T   A fragments straight from the dataset rows (global), B
+//               fragments from a fragment-major LDS image of state_linear / action_linear
+//   + bias + timestep embedding, stacked LayerNorm, block pre-LayerNorm: in the MFMA C layout
+//               (a token's 64 features sit in 4 accumulators x 16 lanes: sums are 4 adds +
+//               4 xor-shuffles)
+//   K | V       [16 x 64] . Wkv^T (64 -> 128): A fragments through LDS (the job's own, not yet
+//               written V rows serve as the transposition scratch), B fragments (the K and V
+//               rows of attention.in_linear) live in 128 VGPRs for the whole kernel
+// Keys are stored as bf16 (ops.py:74-76 casts them), values as fp32.  The last token's query,
+// softmax over all keys (bf16 q.k products and scale as the reference), out projection, MLP,
+// final LayerNorm and value head stay on the vector units: one token per window.
 #include "../../include/iqlhip.h"
 #include "common.h"
 
 namespace iqlhip {
 
 constexpr int E = 64;
+constexpr int PT_WAVES = 8;
+constexpr int VLD = E + 4;  // row stride of the V rows (floats): conflict-free A-fragment reads
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -29,6 +38,11 @@ __device__ __forceinline__ float seg_sum(float v, int width) {  // lanes grouped
   for (int m = width >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m);
   return v;
 }
+__device__ __forceinline__ float sum16(float v) {  // over the 16 lanes that share lane >> 4
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
 // LayerNorm over the 64 lanes (flax/torch: biased variance, eps inside the sqrt)
 __device__ __forceinline__ float layer_norm(float x, float w, float b, float eps) {
   const float mu = wave_sum(x) * (1.0f / E);
@@ -36,49 +50,86 @@ __device__ __forceinline__ float layer_norm(float x, float w, float b, float eps
   const float var = wave_sum(d * d) * (1.0f / E);
   return d / sqrtf(var + eps) * w + b;
 }
+// The same on the MFMA C layout: x[nt][i] = feature 16 nt + (lane & 15) of token row 4 (lane >> 4) + i
+__device__ __forceinline__ void layer_norm_tile(f32x4 (&x)[4], const float (&w)[4], const float (&b)[4],
+                                                float eps) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float mu = sum16((x[0][i] + x[1][i]) + (x[2][i] + x[3][i])) * (1.0f / E);
+    float d[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) d[nt] = x[nt][i] - mu;
+    const float var = sum16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / E);
+    const float rs = sqrtf(var + eps);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) x[nt][i] = d[nt] / rs * w[nt] + b[nt];
+  }
+}
 
-__global__ __launch_bounds__(256) void k_pt_relabel(const iqlhip_pt_weights W, const float *__restrict__ obs,
-                                                    const float *__restrict__ act, int64_t n_rows,
-                                                    const int64_t *__restrict__ win_start,
-                                                    const int32_t *__restrict__ win_len, int64_t n_win,
-                                                    int ql, float *__restrict__ out) {
+constexpr int KCH = 3;  // 16-deep k-steps of the embedding GEMM per register chunk (S, A <= 48: one chunk)
+__global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_weights W,
+                                                               const float *__restrict__ obs,
+                                                               const float *__restrict__ act, int64_t n_rows,
+                                                               const int64_t *__restrict__ win_start,
+                                                               const int32_t *__restrict__ win_len,
+                                                               int64_t n_win, int ql, float *__restrict__ out) {
+  using P = Prec<false>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
   const int S = W.state_dim, A = W.action_dim, I = W.inter_dim, NH = W.num_heads;
   const int HD = E / NH;
   const int Tmax = 2 * ql;
+  const int nks_s = round_up(S, 16) / 16, nks_a = round_up(A, 16) / 16;
   // ---- LDS carve ----
-  float *Vs = reinterpret_cast<float *>(smem);               // [Tmax][64]
-  uint16_t *Kb = reinterpret_cast<uint16_t *>(Vs + (size_t)Tmax * E);  // [Tmax][64] bf16
-  float *wsT = reinterpret_cast<float *>(Kb + (size_t)Tmax * E);       // [S][64]
-  float *waT = wsT + S * E;                                   // [A][64]
-  float *wqT = waT + A * E;                                   // [64][64]
-  float *woT = wqT + E * E;                                   // [64][64]
-  float *hs = woT + E * E;                                    // [4][64] per-wave token scratch
-  float *xlast = hs + 4 * E;                                  // [64]
-  float *hlast = xlast + E;                                   // [64]
-  float *ovec = hlast + E;                                    // [64] attention output / LN1 output
-  float *part = ovec + E;                                     // [4][64] cross-wave partials
-  float *stat = part + 4 * E;                                 // [4 waves][16 heads] x 2
-  float *hid = stat + 2 * 4 * 16;                             // [I]
-  float *lg = hid + I;                                        // [Tmax][NH] logits
+  float *Vs = reinterpret_cast<float *>(smem);                          // [Tmax][VLD]
+  uint16_t *Kb = reinterpret_cast<uint16_t *>(Vs + (size_t)Tmax * VLD);  // [Tmax][64] bf16
+  float *wsF = reinterpret_cast<float *>(Kb + (size_t)Tmax * E);         // fragment-major [64][16 nks_s]
+  float *waF = wsF + nks_s * 16 * E;                                     // fragment-major [64][16 nks_a]
+  float *wqT = waF + nks_a * 16 * E;                                     // [64][64]
+  float *woT = wqT + E * E;                                              // [64][64]
+  float *xlast = woT + E * E;                                            // [64]
+  float *hlast = xlast + E;                                              // [64]
+  float *ovec = hlast + E;                                               // [64] attention output / LN1 output
+  float *part = ovec + E;                                                // [PT_WAVES][64] cross-wave partials
+  float *stat = part + PT_WAVES * E;                                     // [PT_WAVES][16 heads] x 2
+  float *hid = stat + 2 * PT_WAVES * 16;                                 // [I]
+  float *lg = hid + I;                                                   // [Tmax][NH] logits
+  float *fvec = lg + (size_t)Tmax * NH;                                  // [6][64] per-feature vectors
 
   // ---- weights that stay on chip for the whole queue ----
-  for (int e = tid; e < S * E; e += 256) wsT[e] = W.state_wT[e];
-  for (int e = tid; e < A * E; e += 256) waT[e] = W.action_wT[e];
-  for (int e = tid; e < E * E; e += 256) wqT[e] = W.q_wT[e], woT[e] = W.attn_out_wT[e];
-  float wk[E], wv[E];
-#pragma unroll
-  for (int j = 0; j < E; ++j) {
-    wk[j] = W.qkv_w[(size_t)(E + lane) * E + j];
-    wv[j] = W.qkv_w[(size_t)(2 * E + lane) * E + j];
+  // embedding weights as MFMA B fragments (common.h fidx): element (feature f, input k), zero padded
+  for (int e = tid; e < nks_s * 16 * E; e += 64 * PT_WAVES) {
+    const int k = e / E, f = e - k * E;
+    wsF[fidx<P>(f, k, nks_s)] = k < S ? W.state_wT[(size_t)k * E + f] : 0.f;
   }
-  const float bs = W.state_b[lane], ba = W.action_b[lane];
-  const float slw = W.sln_w[lane], slb = W.sln_b[lane];
-  const float l0w = W.ln0_w[lane], l0b = W.ln0_b[lane];
+  for (int e = tid; e < nks_a * 16 * E; e += 64 * PT_WAVES) {
+    const int k = e / E, f = e - k * E;
+    waF[fidx<P>(f, k, nks_a)] = k < A ? W.action_wT[(size_t)k * E + f] : 0.f;
+  }
+  for (int e = tid; e < E * E; e += 64 * PT_WAVES) wqT[e] = W.q_wT[e], woT[e] = W.attn_out_wT[e];
+  // K | V projection (rows 64..191 of attention.in_linear.weight [192][64]) as B fragments:
+  // n-tile nt < 4 -> key features 16 nt.., nt >= 4 -> value features; 4 k-steps of 16
+  uint4 wkv[8][4];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      wkv[nt][ks] = ldg16(W.qkv_w + (size_t)(E + 16 * nt + r) * E + 16 * ks + 4 * q);
+  float bkv[8];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) bkv[nt] = W.qkv_b[E + 16 * nt + r];
+  // per-feature vectors of the token jobs (read from LDS in the C layout: feature 16 nt + r)
+  if (tid < E) {
+    fvec[tid] = W.state_b[tid], fvec[E + tid] = W.action_b[tid];
+    fvec[2 * E + tid] = W.sln_w[tid], fvec[3 * E + tid] = W.sln_b[tid];
+    fvec[4 * E + tid] = W.ln0_w[tid], fvec[5 * E + tid] = W.ln0_b[tid];
+  }
+  // one value per lane (feature = lane) for the last-token phase
   const float l1w = W.ln1_w[lane], l1b = W.ln1_b[lane];
   const float lfw = W.lnf_w[lane], lfb = W.lnf_b[lane];
-  const float bq = W.qkv_b[lane], bk = W.qkv_b[E + lane], bv = W.qkv_b[2 * E + lane];
+  const float bq = W.qkv_b[lane];
   const float bo = W.attn_out_b[lane], bmo = W.mlp_out_b[lane];
   const float pw = W.pref_w_last[lane];
   const float eps = W.eps;
@@ -89,34 +140,109 @@ __global__ __launch_bounds__(256) void k_pt_relabel(const iqlhip_pt_weights W, c
     const int64_t start = win_start[win];
     const int len = win_len[win];
     const int T = 2 * len;
-    // ================= every token: embedding, LN, key / value =================
-    for (int t = wave; t < T; t += 4) {
-      const int k = t >> 1;
-      const int64_t row = start + k;
-      float x;
-      if ((t & 1) == 0) {
-        x = bs;
-        const float *src = obs + (size_t)row * S;
-        for (int j = 0; j < S; ++j) x += src[j] * wsT[j * E + lane];
-      } else {
-        x = ba;
-        const float *src = act + (size_t)row * A;
-        for (int j = 0; j < A; ++j) x += src[j] * waT[j * E + lane];
-      }
-      x += W.temb[(size_t)k * E + lane];  // timestep k of the window (ref:1281,1291)
-      x = layer_norm(x, slw, slb, eps);   // stacked_layer_norm
-      const float h = layer_norm(x, l0w, l0b, eps);  // block pre-LN
-      hs[wave * E + lane] = h;
-      if (t == T - 1) xlast[lane] = x, hlast[lane] = h;
-      float kk = bk, vv = bv;
+    const int nmt = (len + 15) >> 4;  // 16-token tiles per kind
+    // ================= every token: embedding, LayerNorms, key / value =================
+    for (int job = wave; job < 2 * nmt; job += PT_WAVES) {
+      const int kind = job >= nmt ? 1 : 0;  // 0: state tokens, 1: action tokens
+      const int mt = kind ? job - nmt : job;
+      const float *src = kind ? act : obs;
+      const int D = kind ? A : S, nks = kind ? nks_a : nks_s;
+      const float *wF = kind ? waF : wsF;
+      // A fragments from the dataset rows: token 16 mt + r of the window (clamped past len: the
+      // results of those rows are dropped), inputs 16 ks + 4 q .. + 3 (clamped past D: zeroed)
+      const int kr = 16 * mt + r < len ? 16 * mt + r : len - 1;
+      const float *rowp = src + (size_t)(start + kr) * D;
+      // accumulators start from bias + timestep embedding of tokens 4 q + i (timestep = position
+      // in the window, ref:1281,1291)
+      f32x4 x[4];
 #pragma unroll
-      for (int j4 = 0; j4 < E; j4 += 4) {
-        const float4 hv = *reinterpret_cast<const float4 *>(&hs[wave * E + j4]);
-        kk += hv.x * wk[j4] + hv.y * wk[j4 + 1] + hv.z * wk[j4 + 2] + hv.w * wk[j4 + 3];
-        vv += hv.x * wv[j4] + hv.y * wv[j4 + 1] + hv.z * wv[j4 + 2] + hv.w * wv[j4 + 3];
+      for (int i = 0; i < 4; ++i) {
+        const int k = 16 * mt + 4 * q + i < len ? 16 * mt + 4 * q + i : len - 1;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) x[nt][i] = ldg(W.temb + (size_t)k * E + 16 * nt + r);
       }
-      Kb[(size_t)t * E + lane] = f2bf(kk);
-      Vs[(size_t)t * E + lane] = vv;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float bias = fvec[kind * E + 16 * nt + r];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[nt][i] += bias;
+      }
+      for (int ks0 = 0; ks0 < nks; ks0 += KCH) {
+        uint4 a[KCH];
+#pragma unroll
+        for (int kk = 0; kk < KCH; ++kk) {
+          float v[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int k = 16 * (ks0 + kk) + 4 * q + c;
+            const float xv = ldg(rowp + (k < D ? k : D - 1));
+            v[c] = k < D ? xv : 0.f;
+          }
+          a[kk] = __builtin_bit_cast(uint4, make_float4(v[0], v[1], v[2], v[3]));
+        }
+#pragma unroll
+        for (int kk = 0; kk < KCH; ++kk) {
+          if (ks0 + kk < nks) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              const uint4 b = *reinterpret_cast<const uint4 *>(wF + frag_off<P>(nt, ks0 + kk, nks, lane));
+              P::mma(a[kk], b, x[nt]);
+            }
+          }
+        }
+      }
+      float lw[4], lb[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) lw[nt] = fvec[2 * E + 16 * nt + r], lb[nt] = fvec[3 * E + 16 * nt + r];
+      layer_norm_tile(x, lw, lb, eps);  // stacked_layer_norm
+      f32x4 h[4] = {x[0], x[1], x[2], x[3]};
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) lw[nt] = fvec[4 * E + 16 * nt + r], lb[nt] = fvec[5 * E + 16 * nt + r];
+      layer_norm_tile(h, lw, lb, eps);  // block pre-LN
+      // the window's last token (action token len - 1) feeds the query / residual path
+      if (kind == 1 && mt == nmt - 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (16 * mt + 4 * q + i == len - 1) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) xlast[16 * nt + r] = x[nt][i], hlast[16 * nt + r] = h[nt][i];
+          }
+        }
+      }
+      // h -> A fragments through the job's own V rows (token j of the tile -> row 2 (16 mt + j) + kind)
+      float *scr = Vs + (size_t)(2 * 16 * mt + kind) * VLD;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (16 * mt + 4 * q + i < ql) scr[(size_t)(4 * q + i) * 2 * VLD + 16 * nt + r] = h[nt][i];
+      // same wave, LDS operations execute in order: only the compiler must keep the order
+      asm volatile("" ::: "memory");
+      uint4 ha[4];
+      const int rr = 16 * mt + r < ql ? r : 0;  // rows past the LDS image (never stored) re-read row 0
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        ha[ks] = *reinterpret_cast<const uint4 *>(scr + (size_t)rr * 2 * VLD + 16 * ks + 4 * q);
+      asm volatile("" ::: "memory");  // the V rows written below are the scratch read above
+      f32x4 kv[8];
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) kv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) P::mma(ha[ks], wkv[nt][ks], kv[nt]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = 16 * mt + 4 * q + i;
+        if (k < len) {
+          const int t = 2 * k + kind;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            Kb[(size_t)t * E + 16 * nt + r] = f2bf(kv[nt][i] + bkv[nt]);
+            Vs[(size_t)t * VLD + 16 * nt + r] = kv[4 + nt][i] + bkv[4 + nt];
+          }
+        }
+      }
     }
     __syncthreads();
     // ================= last token: query, attention over all keys =================
@@ -126,7 +252,7 @@ __global__ __launch_bounds__(256) void k_pt_relabel(const iqlhip_pt_weights W, c
     const float qb = rbf(qv);  // ops.py:74
     const int head = lane / HD;
     float lmax = -3.0e38f;
-    for (int t = wave; t < T; t += 4) {
+    for (int t = wave; t < T; t += PT_WAVES) {
       float s = seg_sum(qb * bf2f(Kb[(size_t)t * E + lane]), HD);
       s = rbf(rbf(s) * inv_sqrt_hd);  // bf16 product tensor, bf16 scale (ops.py:76-79)
       if ((lane % HD) == 0) lg[t * NH + head] = s;
@@ -136,19 +262,20 @@ __global__ __launch_bounds__(256) void k_pt_relabel(const iqlhip_pt_weights W, c
     __syncthreads();
     float gmax = stat[head];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) gmax = fmaxf(gmax, stat[w * 16 + head]);
+    for (int w = 1; w < PT_WAVES; ++w) gmax = fmaxf(gmax, stat[w * 16 + head]);
     float lsum = 0.f, oacc = 0.f;
-    for (int t = wave; t < T; t += 4) {
+    for (int t = wave; t < T; t += PT_WAVES) {
       const float p = expf(lg[t * NH + head] - gmax);
       lsum += p;
-      oacc += p * Vs[(size_t)t * E + lane];
+      oacc += p * Vs[(size_t)t * VLD + lane];
     }
     part[wave * E + lane] = oacc;
-    if ((lane % HD) == 0) stat[64 + wave * 16 + head] = lsum;
+    if ((lane % HD) == 0) stat[PT_WAVES * 16 + wave * 16 + head] = lsum;
     __syncthreads();
     {
-      float o = part[lane] + part[E + lane] + part[2 * E + lane] + part[3 * E + lane];
-      const float den = stat[64 + head] + stat[64 + 16 + head] + stat[64 + 32 + head] + stat[64 + 48 + head];
+      float o = 0.f, den = 0.f;
+#pragma unroll
+      for (int w = 0; w < PT_WAVES; ++w) o += part[w * E + lane], den += stat[PT_WAVES * 16 + w * 16 + head];
       if (wave == 0) ovec[lane] = o / den;
     }
     __syncthreads();
@@ -161,23 +288,26 @@ __global__ __launch_bounds__(256) void k_pt_relabel(const iqlhip_pt_weights W, c
     if (wave == 0) ovec[lane] = h1;
     __syncthreads();
     // ---- MLP: hidden units j = lane + 64 m, m split over the waves ----
-    for (int m = wave; m < I / E; m += 4) {
+    for (int m = wave; m < I / E; m += PT_WAVES) {
       const int j = lane + E * m;
-      float a = W.mlp_in_b[j];
+      float acc = W.mlp_in_b[j];
 #pragma unroll 8
-      for (int e = 0; e < E; ++e) a += ovec[e] * W.mlp_in_wT[(size_t)e * I + j];
-      hid[j] = fmaxf(a, 0.f);
+      for (int e = 0; e < E; ++e) acc += ovec[e] * W.mlp_in_wT[(size_t)e * I + j];
+      hid[j] = fmaxf(acc, 0.f);
     }
     __syncthreads();
     {
-      const int j0 = wave * (I / 4), j1 = j0 + I / 4;
-      float a = 0.f;
-      for (int j = j0; j < j1; ++j) a += hid[j] * W.mlp_out_wT[(size_t)j * E + lane];
-      part[wave * E + lane] = a;
+      const int j0 = wave * (I / PT_WAVES), j1 = j0 + I / PT_WAVES;
+      float acc = 0.f;
+#pragma unroll 8
+      for (int j = j0; j < j1; ++j) acc += hid[j] * W.mlp_out_wT[(size_t)j * E + lane];
+      part[wave * E + lane] = acc;
     }
     __syncthreads();
     if (wave == 0) {
-      const float x2 = bmo + part[lane] + part[E + lane] + part[2 * E + lane] + part[3 * E + lane] + x1;
+      float x2 = bmo + x1;
+#pragma unroll
+      for (int w = 0; w < PT_WAVES; ++w) x2 += part[w * E + lane];
       const float y = layer_norm(x2, lfw, lfb, eps);  // gpt.layer_norm
       const float v = wave_sum(y * pw) + W.pref_b_last;
       if (lane == 0) out[win] = v;
@@ -188,20 +318,27 @@ __global__ __launch_bounds__(256) void k_pt_relabel(const iqlhip_pt_weights W, c
 
 size_t pt_smem_bytes(const iqlhip_pt_weights &W, int ql) {
   const size_t Tmax = 2 * (size_t)ql;
-  return Tmax * E * 4 + Tmax * E * 2 + (size_t)(W.state_dim + W.action_dim) * E * 4 + 2 * E * E * 4 +
-         (4 * E + 3 * E + 4 * E + 2 * 4 * 16 + W.inter_dim + Tmax * W.num_heads) * 4 + 64;
+  const size_t ks = (size_t)round_up(W.state_dim, 16) + round_up(W.action_dim, 16);
+  return Tmax * VLD * 4 + Tmax * E * 2 + ks * E * 4 + 2 * E * E * 4 +
+         (3 * E + PT_WAVES * E + 2 * PT_WAVES * 16 + W.inter_dim + Tmax * W.num_heads + 6 * E) * 4 + 64;
 }
 
 hipError_t launch_pt(const iqlhip_pt_weights &W, const float *obs, const float *act, int64_t n_rows,
                      const int64_t *win_start, const int32_t *win_len, int64_t n_win, int ql, float *out,
                      hipStream_t st) {
   const size_t sm = pt_smem_bytes(W, ql);
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  // persistent work-groups: as many as stay resident
+  const int per_cu = 1;  // 8 waves of ~250 VGPRs: one work-group per CU
+  int64_t grid = (int64_t)cus * per_cu;
+  if (n_win < grid) grid = n_win;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pt_relabel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
-  int64_t grid = n_win < 1024 ? n_win : 1024;  // 4 work-groups per CU queue the windows
-  hipLaunchKernelGGL(k_pt_relabel, dim3((unsigned)grid), dim3(256), sm, st, W, obs, act, n_rows, win_start,
-                     win_len, n_win, ql, out);
+  hipLaunchKernelGGL(k_pt_relabel, dim3((unsigned)grid), dim3(64 * PT_WAVES), sm, st, W, obs, act, n_rows,
+                     win_start, win_len, n_win, ql, out);
   return hipGetLastError();
 }
 
