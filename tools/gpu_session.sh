@@ -1,0 +1,35 @@
+#!/bin/bash
+# One GPU-box session (each gpurun call pays ~10 min to get a box: do everything in one):
+#   tools/gpu_session.sh <tag> [tests] [stamps] [relabel] [bench] [bench20] [profile]
+TAG=$1; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+for what in "$@"; do
+  case $what in
+    tests)
+      IQL_TEST_DIAG=$OUT/diag.txt timeout -k 10 900 python -m pytest tests -m gpu -q -x > $OUT/tests.log 2>&1
+      echo "tests rc=$?"; tail -4 $OUT/tests.log | cut -c1-300 ;;
+    testsall)
+      IQL_TEST_DIAG=$OUT/diag.txt timeout -k 10 900 python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1
+      echo "tests rc=$?"; tail -12 $OUT/tests.log | cut -c1-300 ;;
+    stamps)
+      for k in 0 1 2; do
+        STAMP_GRAPH=8 STAMP_KERNEL=$k timeout -k 10 120 python tools/stamps.py bf16 > $OUT/stamps_k$k.txt 2>&1 || echo "stamps $k failed"
+      done
+      head -40 $OUT/stamps_k2.txt ;;
+    relabel)
+      timeout -k 10 300 python tools/bench_relabel.py --cpu > $OUT/relabel.json 2> $OUT/relabel.err
+      echo "relabel rc=$?"; cat $OUT/relabel.json | head -120 ;;
+    bench)
+      timeout -k 10 300 python bench.py --no-cpu-baseline --no-relabel > $OUT/bench.json 2> $OUT/bench.err
+      echo "bench rc=$?"; python -c "
+import json; d=json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])
+print('value', round(d['value']), d['roofline']['step']['kernel_us'], 'frac', round(d['roofline']['frac'],3))
+print('agents', d.get('agents_per_gpu',{}).get('value'), 'ensemble', d.get('ensemble_q',{}).get('value'))" ;;
+    bench20)
+      timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/bench20.err
+      echo "bench20 rc=$?"; tail -c 1500 $OUT/bench20.json ;;
+    profile)
+      bash tools/profile.sh $TAG > $OUT/profile.log 2>&1; echo "profile rc=$?"; tail -5 $OUT/profile.log ;;
+  esac
+done
