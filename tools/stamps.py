@@ -10,9 +10,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# an explicitly named build is loaded as it is (no source-tag check): the diagnostic library
+os.environ["IQLHIP_LIB"] = os.path.join(ROOT, "iqlpref_amd", "libiqlhip_stamps.so")
 from iqlpref_amd import _lib  # noqa: E402
-
-_lib.LIB_PATH = os.path.join(ROOT, "iqlpref_amd", "libiqlhip_stamps.so")
 import iqlpref_amd as ia  # noqa: E402
 import bench  # noqa: E402
 
