@@ -61,8 +61,9 @@ const char *iqlhip_build_tag(void);
 /* Replay buffer  (ref:164-226 ReplayBuffer)                                 */
 /*                                                                           */
 /* Storage is ONE row-major fp32 matrix [capacity][row_stride]; row i holds  */
-/* transition i as  [ s(S) | a(A) | r | d | s'(S) | pad ]  so that one       */
-/* sample is one contiguous, 16-byte aligned read instead of five.           */
+/* transition i as  [ s(S) | a(A) | r | d | pad | s'(S) | pad ]  with s' on a */
+/* 16-byte boundary (float offset iqlhip_replay_next_offset), so that one    */
+/* sample is one contiguous read of aligned 16-byte pieces instead of five.  */
 /* ------------------------------------------------------------------------ */
 typedef struct {
   const float *rows;  /* device, [n_rows][row_stride]          */
@@ -72,7 +73,9 @@ typedef struct {
   int32_t action_dim;
 } iqlhip_replay_view;
 
-/* Row stride (floats) for the given dims: 2S+A+2 rounded up to a multiple of 4. */
+/* Float offset of s' inside a row: S+A+2 rounded up to a multiple of 4; row stride (floats):
+ * that offset + S, rounded up to a multiple of 4.  Views must carry exactly this stride.  */
+int32_t iqlhip_replay_next_offset(int32_t state_dim, int32_t action_dim);
 int32_t iqlhip_replay_row_stride(int32_t state_dim, int32_t action_dim);
 
 /* ref:193-209 load_d4rl_dataset: interleave the five device arrays
@@ -157,7 +160,8 @@ typedef struct {
   int32_t n_critics;     /* 0 or 2: TwinQ (ref:517-533); 3..8: E-way critic ensemble,
                             the same MLP E times, q_target = min over E, q_loss =
                             sum(mse)/E (ref:606 generalised; SURVEY 8 "config 5")    */
-  int32_t reserved;
+  int32_t polyak_form;   /* target update: 0 = tp.lerp_(sp, tau) (offline/iql.py:127-129),
+                            1 = (1 - tau) tp + tau sp (custom_offline/iql.py:85-87)      */
 } iqlhip_trainer_config;
 
 /* Number of fp32 elements of the arenas (n_params, n_target: they include the
@@ -310,12 +314,17 @@ typedef struct {
 
 /* out[w] = value[:, 0, -1, 0] (ref:1301) of the window of win_len[w] consecutive
  * transitions obs/act[win_start[w] .. +win_len[w]), right-aligned in a
- * query_length window with timesteps 0..len-1 (ref:1269-1292).
+ * query_length window (ref:1269-1292); the timestep of the window's k-th transition is
+ * win_t0[w] + k.  win_t0 == NULL: 0 for every window (ref:1281,1291: timesteps 0..len-1);
+ * custom_offline/iql.py:183-211 passes the true episode step (win_t0[w] + len <= n_temb is the
+ * caller's to guarantee).  Because attention is causal, the value at position i of ONE forward
+ * over a window (custom_offline:172-192) equals the last-token value of its prefix of length
+ * i + 1: per-position values are windows of growing length.
  * obs [n_rows][S], act [n_rows][A], win_start int64 [n_win], win_len int32
- * [n_win] (1 <= len <= query_length), all device.                            */
+ * [n_win] (1 <= len <= query_length), win_t0 int32 [n_win] or NULL, all device.  */
 int iqlhip_pt_relabel(const iqlhip_pt_weights *w, const float *obs, const float *act, int64_t n_rows,
-                      const int64_t *win_start, const int32_t *win_len, int64_t n_win,
-                      int32_t query_length, float *out, void *stream);
+                      const int64_t *win_start, const int32_t *win_len, const int32_t *win_t0,
+                      int64_t n_win, int32_t query_length, float *out, void *stream);
 
 /* Algorithmic traffic and work of one step for this configuration
  * (SURVEY.md section 8d): bytes = 4B(2S+A+2) + 32 P_train + 8 P_q.          */

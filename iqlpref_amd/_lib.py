@@ -40,7 +40,7 @@ class TrainerConfig(C.Structure):
                 ("adam_beta1", C.c_double), ("adam_beta2", C.c_double),
                 ("adam_eps", C.c_double),
                 ("cosine_t_max", C.c_int64), ("seed", C.c_uint64),
-                ("n_critics", C.c_int32), ("reserved", C.c_int32)]
+                ("n_critics", C.c_int32), ("polyak_form", C.c_int32)]
 
 
 class Arenas(C.Structure):
@@ -74,6 +74,7 @@ SYMBOLS = {
     "iqlhip_abi_version": (C.c_int, []),
     "iqlhip_build_tag": (C.c_char_p, []),
     "iqlhip_replay_row_stride": (C.c_int32, [C.c_int32, C.c_int32]),
+    "iqlhip_replay_next_offset": (C.c_int32, [C.c_int32, C.c_int32]),
     "iqlhip_replay_pack": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
                                      P, P, P, P, P, P]),
     "iqlhip_replay_pack_normalized": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
@@ -103,7 +104,7 @@ SYMBOLS = {
     "iqlhip_forward": (C.c_int, [P, C.c_int32, P, P, C.c_int64, P, P]),
     "iqlhip_mlp_forward": (C.c_int, [C.POINTER(MlpDesc), P, C.c_int64, C.c_int32, P, C.c_int32, P]),
     "iqlhip_cvar_tail_mean": (C.c_int, [P, C.c_int32, C.c_int64, C.c_int32, P, P]),
-    "iqlhip_pt_relabel": (C.c_int, [C.POINTER(PtWeights), P, P, C.c_int64, P, P, C.c_int64, C.c_int32,
+    "iqlhip_pt_relabel": (C.c_int, [C.POINTER(PtWeights), P, P, C.c_int64, P, P, P, C.c_int64, C.c_int32,
                                     P, P]),
     "iqlhip_step_cost": (C.c_int, [C.POINTER(TrainerConfig), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),

@@ -20,7 +20,10 @@ hipError_t launch_forward(bool, const TrainerDesc &, const TrainerDesc *, const 
                           int n_seeds, hipStream_t);
 hipError_t launch_backward(bool, const TrainerDesc &, const TrainerDesc *, const DevArgs *, DevCtr *,
                            int n_seeds, hipStream_t);
+hipError_t launch_stage(const TrainerDesc &, const TrainerDesc *, const DevArgs *, const DevCtr *, int n_seeds,
+                        hipStream_t);
 int strip_rows();
+int update_lds_floats();
 hipError_t launch_update(bool, const TrainerDesc *, const DevArgs *, DevCtr *, const UpdItem *, int,
                          int n_seeds, hipStream_t);
 hipError_t launch_sync_weights(bool, const TrainerDesc *, hipStream_t);
@@ -50,8 +53,8 @@ hipError_t launch_pack_norm(float *rows, int stride, int S, int A, int64_t first
                             const float *mean, const float *sd, hipStream_t st);
 size_t pt_smem_bytes(const iqlhip_pt_weights &W, int ql);
 hipError_t launch_pt(const iqlhip_pt_weights &W, const float *obs, const float *act, int64_t n_rows,
-                     const int64_t *win_start, const int32_t *win_len, int64_t n_win, int ql, float *out,
-                     hipStream_t st);
+                     const int64_t *win_start, const int32_t *win_len, const int32_t *win_t0, int64_t n_win,
+                     int ql, float *out, hipStream_t st);
 }  // namespace iqlhip
 
 using namespace iqlhip;
@@ -84,13 +87,17 @@ static const char g_build_tag[] = "IQLHIP_BUILD_TAG=" IQLHIP_BUILD_TAG;  // mark
 extern "C" const char *iqlhip_build_tag(void) { return g_build_tag + sizeof("IQLHIP_BUILD_TAG=") - 1; }
 
 // ------------------------------------------------------------------ replay --
-extern "C" int32_t iqlhip_replay_row_stride(int32_t S, int32_t A) { return round_up(2 * S + A + 2, 4); }
+// Packed replay row: [ s(S) | a(A) | r | d | pad | s'(S) | pad ], s' on a 16-byte boundary
+extern "C" int32_t iqlhip_replay_next_offset(int32_t S, int32_t A) { return round_up(S + A + 2, 4); }
+extern "C" int32_t iqlhip_replay_row_stride(int32_t S, int32_t A) {
+  return round_up(iqlhip_replay_next_offset(S, A) + S, 4);
+}
 
 extern "C" int iqlhip_replay_pack(float *rows, int32_t row_stride, int32_t S, int32_t A, int64_t first_row,
                                   int64_t n, const float *obs, const float *act, const float *rew,
                                   const float *next_obs, const float *done, void *stream) {
   if (!rows || !obs || !act || !rew || !next_obs || !done) return fail(IQLHIP_ERR_INVALID, "null pointer");
-  if (S <= 0 || A <= 0 || n < 0 || first_row < 0 || row_stride < 2 * S + A + 2 || (row_stride & 3))
+  if (S <= 0 || A <= 0 || n < 0 || first_row < 0 || row_stride < iqlhip_replay_row_stride(S, A) || (row_stride & 3))
     return fail(IQLHIP_ERR_INVALID, "bad replay geometry S=%d A=%d stride=%d", S, A, row_stride);
   if (n == 0) return 0;
   HIP_TRY(launch_pack(rows, row_stride, S, A, first_row, n, obs, act, rew, next_obs, done,
@@ -104,7 +111,7 @@ extern "C" int iqlhip_replay_pack_normalized(float *rows, int32_t row_stride, in
                                              const float *mean, const float *std, void *stream) {
   if (!rows || !obs || !act || !rew || !next_obs || !done || !mean || !std)
     return fail(IQLHIP_ERR_INVALID, "null pointer");
-  if (S <= 0 || A <= 0 || n < 0 || first_row < 0 || row_stride < 2 * S + A + 2 || (row_stride & 3))
+  if (S <= 0 || A <= 0 || n < 0 || first_row < 0 || row_stride < iqlhip_replay_row_stride(S, A) || (row_stride & 3))
     return fail(IQLHIP_ERR_INVALID, "bad replay geometry S=%d A=%d stride=%d", S, A, row_stride);
   if (n == 0) return 0;
   HIP_TRY(launch_pack_norm(rows, row_stride, S, A, first_row, n, obs, act, rew, next_obs, done, mean, std,
@@ -188,7 +195,6 @@ struct iqlhip_trainer {
   struct iqlhip_group *group = nullptr;
 
   float *batch_rows = nullptr;  // [B][stride] staging for iqlhip_train_batch
-  int64_t call_id = 0;          // tags the batches prefetched during one run_steps call
   // DevArgs travel through a small ring of pinned host slots (a pageable source makes
   // hipMemcpyAsync host-blocking, which serialised the streams of a SeedGroup); a slot is
   // reused only after the copy that read it has completed (its event)
@@ -228,13 +234,16 @@ static int check_cfg(const iqlhip_trainer_config *c) {
     return fail(IQLHIP_ERR_UNSUPPORTED, "batch_size %d: must be a positive multiple of 16", c->batch_size);
   if (c->action_dim > 32) return fail(IQLHIP_ERR_UNSUPPORTED, "action_dim %d > 32", c->action_dim);
   if (c->state_dim + c->action_dim > 128) return fail(IQLHIP_ERR_UNSUPPORTED, "state_dim+action_dim > 128");
-  if ((c->batch_size / 16) * (n_critics(*c) + 2 + (c->deterministic ? 0 : c->action_dim)) > 8000)
+  // the misc block of k_update sums the per-slab loss partials in its LDS
+  if ((c->batch_size / 16) * (n_critics(*c) + 2 + (c->deterministic ? 0 : c->action_dim)) + n_critics(*c) + 2 >
+      update_lds_floats())
     return fail(IQLHIP_ERR_UNSUPPORTED, "batch_size %d too large for action_dim %d", c->batch_size,
                 c->action_dim);
   if (c->precision != IQLHIP_PREC_FP32 && c->precision != IQLHIP_PREC_BF16)
     return fail(IQLHIP_ERR_INVALID, "precision must be IQLHIP_PREC_FP32 or IQLHIP_PREC_BF16");
   if (c->dropout_p >= 1.0f) return fail(IQLHIP_ERR_INVALID, "dropout_p must be < 1");
   if (c->cosine_t_max <= 0) return fail(IQLHIP_ERR_INVALID, "cosine_t_max must be positive");
+  if (c->polyak_form != 0 && c->polyak_form != 1) return fail(IQLHIP_ERR_INVALID, "polyak_form must be 0 or 1");
   return 0;
 }
 
@@ -342,6 +351,8 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   D.deterministic = cfg->deterministic;
   D.has_dropout = cfg->dropout_p > 0.f;
   D.discount = cfg->discount, D.tau = cfg->tau, D.beta = cfg->beta, D.iql_tau = cfg->iql_tau;
+  D.one_m_tau = (float)(1.0 - (double)cfg->tau);
+  D.polyak_convex = cfg->polyak_form == 1;
   if (D.has_dropout) {
     const float scale = 1.0f / (float)(1.0 - (double)cfg->dropout_p);
     if (t->bf16) {  // noise.div_(1-p) happens in bf16 under autocast (ATen _dropout_impl)
@@ -379,6 +390,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
       add((size_t)outpad[n] * H * es);
     }
     add((size_t)H * H * es);  // w2ct
+    add((size_t)H * outpad[n] * es);  // w3t
   }
   add((size_t)D.xrows * D.BP * es);
   add((size_t)B * 2 * 4);
@@ -467,6 +479,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
       N.tc[2] = carve<char>(p, (size_t)outpad[n] * H * es);
     }
     N.w2ct = carve<char>(p, (size_t)H * H * es);
+    N.w3t = carve<char>(p, (size_t)H * outpad[n] * es);
   }
   D.xT = carve<char>(p, (size_t)D.xrows * D.BP * es);
   D.rd = carve<float>(p, (size_t)B * 2);
@@ -482,7 +495,10 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   t->batch_rows = carve<float>(p, (size_t)B * stride);
   D.stage_rows = carve<float>(p, (size_t)B * stride);
   D.stage_stride = stride;
-  if (n_pad == 0 || getenv("IQLHIP_NO_PREFETCH")) D.stage_rows = nullptr;
+  D.next_off = iqlhip_replay_next_offset(S, A);
+  // the idle slots of the update kernel gather the next step's batch; without them (or with
+  // IQLHIP_NO_PREFETCH, the A/B of tests/test_gpu_step.py) k_stage runs before every step
+  D.prefetch = (n_pad > 0 && !getenv("IQLHIP_NO_PREFETCH")) ? 1 : 0;
   t->own_dargs = t->dargs = carve<DevArgs>(p, 1);
   t->own_dctr = t->dctr = carve<DevCtr>(p, 1);
   t->own_ddesc = t->ddesc = carve<TrainerDesc>(p, 1);
@@ -501,6 +517,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
     it.off_w = N.off_w[L], it.off_b = N.off_b[L], it.toff_w = N.toff_w[L], it.toff_b = N.toff_b[L];
 
     it.wc = N.wc[L], it.tc = N.has_target ? N.tc[L] : nullptr, it.w2ct = (L == 1) ? N.w2ct : nullptr;
+    it.w3t = (L == 2) ? N.w3t : nullptr;
     const size_t plane = (size_t)H * D.BP * es;
     it.Xsrc = (L == 0) ? D.xT : reinterpret_cast<char *>(D.hT) + (size_t)(it.net * 2 + (L - 1)) * plane;
     it.Zsrc = (L == 0)   ? reinterpret_cast<char *>(D.dz1T) + (size_t)it.net * plane
@@ -535,7 +552,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   mk(E, D.net_v, false, 0, D.out_v, D.net_v);
   mk(E + 1, D.net_a, false, 0, D.out_mean, D.net_a);
   for (int e = 0; e < E; ++e) mk(E + 2 + e, e, true, 0, D.out_qt + e, -1);
-  mk(2 * E + 2, D.net_v, false, S + A + 2, D.out_nv, -1);
+  mk(2 * E + 2, D.net_v, false, D.next_off, D.out_nv, -1);
 
   if (hipMemcpy(t->ddesc, &t->D, sizeof(TrainerDesc), hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipFree(t->ws);
@@ -578,7 +595,6 @@ extern "C" int iqlhip_trainer_set_step(iqlhip_trainer *t, int64_t total_it) {
   DevCtr c;
   memset(&c, 0, sizeof(c));
   c.ctr[0] = total_it, c.ctr[1] = total_it;
-  c.staged_step = -1;
   HIP_TRY(hipMemcpy(t->dctr, &c, sizeof(c), hipMemcpyHostToDevice));
   return 0;
 }
@@ -624,6 +640,7 @@ extern "C" int iqlhip_trainer_get_timing(iqlhip_trainer *t, double avg_ms[3], in
 }
 
 static int enqueue_step(iqlhip_trainer *t, hipStream_t st) {
+  if (!t->D.prefetch) HIP_TRY(launch_stage(t->D, t->ddesc, t->dargs, t->dctr, 1, st));
   HIP_TRY(launch_forward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, 1, st));
   HIP_TRY(launch_backward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, 1, st));
   HIP_TRY(launch_update(t->bf16, t->ddesc, t->dargs, t->dctr, t->ditems, t->n_items, 1, st));
@@ -633,7 +650,6 @@ static int enqueue_step(iqlhip_trainer *t, hipStream_t st) {
 static hipError_t push_args(iqlhip_trainer *t, const DevArgs &args_in, int64_t n_steps, hipStream_t st) {
   DevArgs args = args_in;
   args.n_steps = n_steps;
-  args.call_id = ++t->call_id;
   const int k = t->harg_head;
   t->harg_head = (k + 1) % iqlhip_trainer::ARG_RING;
   hipError_t e;
@@ -653,10 +669,13 @@ static hipError_t push_args(iqlhip_trainer *t, const DevArgs &args_in, int64_t n
 static int run_steps(iqlhip_trainer *t, const DevArgs &args_in, int64_t n_steps, int graph_unroll,
                      hipStream_t st) {
   HIP_TRY(push_args(t, args_in, n_steps, st));
+  // the first step's batch (later steps are staged by the update kernel of the step before)
+  if (t->D.prefetch) HIP_TRY(launch_stage(t->D, t->ddesc, t->dargs, t->dctr, 1, st));
   int64_t done = 0;
   if (t->timing) {
     // one event pair per kernel: serialises the stream a little; diagnostic mode only
     for (; done < n_steps; ++done) {
+      if (!t->D.prefetch) HIP_TRY(launch_stage(t->D, t->ddesc, t->dargs, t->dctr, 1, st));
       HIP_TRY(hipEventRecord(t->ev[0], st));
       HIP_TRY(launch_forward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, 1, st));
       HIP_TRY(hipEventRecord(t->ev[1], st));
@@ -712,8 +731,9 @@ extern "C" int iqlhip_train_steps(iqlhip_trainer *t, const iqlhip_replay_view *v
     return fail(IQLHIP_ERR_INVALID, "replay dims (%d,%d) do not match the trainer (%d,%d)", view->state_dim,
                 view->action_dim, t->cfg.state_dim, t->cfg.action_dim);
   if (view->n_rows <= 0) return fail(IQLHIP_ERR_INVALID, "cannot sample from an empty replay buffer");
-  if (view->row_stride < 2 * view->state_dim + view->action_dim + 2)
-    return fail(IQLHIP_ERR_INVALID, "row_stride too small");
+  if (view->row_stride != iqlhip_replay_row_stride(view->state_dim, view->action_dim))
+    return fail(IQLHIP_ERR_INVALID, "row_stride %d is not the packed layout's (%d)", view->row_stride,
+                iqlhip_replay_row_stride(view->state_dim, view->action_dim));
   if (n_steps == 0) return 0;
   DevArgs a;
   memset(&a, 0, sizeof(a));
@@ -774,7 +794,7 @@ struct iqlhip_group {
 static bool same_shape(const iqlhip_trainer_config &a, const iqlhip_trainer_config &b) {
   return a.state_dim == b.state_dim && a.action_dim == b.action_dim && a.hidden_dim == b.hidden_dim &&
          a.batch_size == b.batch_size && a.deterministic == b.deterministic && a.precision == b.precision &&
-         n_critics(a) == n_critics(b) && (a.dropout_p > 0.f) == (b.dropout_p > 0.f);
+         n_critics(a) == n_critics(b) && (a.dropout_p > 0.f) == (b.dropout_p > 0.f);  // (polyak_form: per seed)
 }
 
 extern "C" int iqlhip_group_create(iqlhip_group **out, iqlhip_trainer *const *trainers, int32_t n) {
@@ -862,6 +882,7 @@ extern "C" int iqlhip_group_destroy(iqlhip_group *g) {
 
 static int group_enqueue_step(iqlhip_group *g, hipStream_t st) {
   iqlhip_trainer *t0 = g->tr[0];
+  if (!t0->D.prefetch) HIP_TRY(launch_stage(t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
   HIP_TRY(launch_forward(t0->bf16, t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
   HIP_TRY(launch_backward(t0->bf16, t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
   HIP_TRY(launch_update(t0->bf16, g->gdesc, g->gargs, g->gctr, g->gitems, t0->n_items, g->K, st));
@@ -881,7 +902,8 @@ extern "C" int iqlhip_group_train_steps(iqlhip_group *g, const iqlhip_replay_vie
       return fail(IQLHIP_ERR_INVALID, "replay dims (%d,%d) do not match the trainer (%d,%d)", v.state_dim,
                   v.action_dim, c.state_dim, c.action_dim);
     if (v.n_rows <= 0) return fail(IQLHIP_ERR_INVALID, "cannot sample from an empty replay buffer");
-    if (v.row_stride < 2 * v.state_dim + v.action_dim + 2) return fail(IQLHIP_ERR_INVALID, "row_stride too small");
+    if (v.row_stride != iqlhip_replay_row_stride(v.state_dim, v.action_dim))
+      return fail(IQLHIP_ERR_INVALID, "row_stride %d is not the packed layout's", v.row_stride);
   }
   if (n_steps == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -905,12 +927,12 @@ extern "C" int iqlhip_group_train_steps(iqlhip_group *g, const iqlhip_replay_vie
     a.base_step = t->total_it;
     a.lr_q = t->lr_q, a.lr_v = t->lr_v, a.lr_a_base = t->lr_a_base;
     a.n_steps = n_steps;
-    a.call_id = ++t->call_id;
     g->harg[slot][k] = a;
   }
   HIP_TRY(hipMemcpyAsync(g->gargs, g->harg[slot], sizeof(DevArgs) * g->K, hipMemcpyHostToDevice, st));
   HIP_TRY(hipEventRecord(g->harg_ev[slot], st));
   g->harg_used[slot] = true;
+  if (g->tr[0]->D.prefetch) HIP_TRY(launch_stage(g->tr[0]->D, g->gdesc, g->gargs, g->gctr, g->K, st));
   // ---- the steps: hipGraphs of `graph_unroll` steps, the remainder eagerly ----
   int64_t done = 0;
   if (graph_unroll > 0 && n_steps >= graph_unroll) {
@@ -1015,7 +1037,8 @@ extern "C" int iqlhip_cvar_tail_mean(const float *preds, int32_t S, int64_t N, i
 
 extern "C" int iqlhip_pt_relabel(const iqlhip_pt_weights *w, const float *obs, const float *act,
                                  int64_t n_rows, const int64_t *win_start, const int32_t *win_len,
-                                 int64_t n_win, int32_t query_length, float *out, void *stream) {
+                                 const int32_t *win_t0, int64_t n_win, int32_t query_length, float *out,
+                                 void *stream) {
   if (!w || !obs || !act || !win_start || !win_len || !out) return fail(IQLHIP_ERR_INVALID, "null argument");
   if (n_win <= 0 || n_rows <= 0 || query_length < 1) return fail(IQLHIP_ERR_INVALID, "empty problem");
   if (w->embd_dim != 64) return fail(IQLHIP_ERR_UNSUPPORTED, "embd_dim %d: the kernel is built for 64", w->embd_dim);
@@ -1026,9 +1049,11 @@ extern "C" int iqlhip_pt_relabel(const iqlhip_pt_weights *w, const float *obs, c
     return fail(IQLHIP_ERR_UNSUPPORTED, "inter_dim %d: must be a multiple of 256 up to 1024", w->inter_dim);
   if (w->state_dim < 1 || w->action_dim < 1 || w->state_dim + w->action_dim > 192)
     return fail(IQLHIP_ERR_UNSUPPORTED, "state/action dims");
-  if (query_length > w->n_temb) return fail(IQLHIP_ERR_INVALID, "query_length exceeds the timestep table");
+  if (!win_t0 && query_length > w->n_temb)
+    return fail(IQLHIP_ERR_INVALID, "query_length exceeds the timestep table");
   if (pt_smem_bytes(*w, query_length) > 160 * 1024)
     return fail(IQLHIP_ERR_UNSUPPORTED, "query_length %d does not fit the 160 KiB LDS", query_length);
-  HIP_TRY(launch_pt(*w, obs, act, n_rows, win_start, win_len, n_win, query_length, out, (hipStream_t)stream));
+  HIP_TRY(launch_pt(*w, obs, act, n_rows, win_start, win_len, win_t0, n_win, query_length, out,
+                    (hipStream_t)stream));
   return 0;
 }

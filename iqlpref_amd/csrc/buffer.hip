@@ -11,7 +11,7 @@ __global__ void k_pack(float *__restrict__ rows, int stride, int S, int A, int64
                        const float *__restrict__ obs, const float *__restrict__ act,
                        const float *__restrict__ rew, const float *__restrict__ nxt,
                        const float *__restrict__ done) {
-  const int W = 2 * S + A + 2;
+  const int NO = round_up(S + A + 2, 4), W = NO + S;  // s' starts on a 16-byte boundary
   const int64_t total = n * (int64_t)stride;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
@@ -26,8 +26,8 @@ __global__ void k_pack(float *__restrict__ rows, int stride, int S, int A, int64
       v = rew[row];
     else if (c == S + A + 1)
       v = done[row];
-    else if (c < W)
-      v = nxt[row * S + (c - S - A - 2)];
+    else if (c >= NO && c < W)
+      v = nxt[row * S + (c - NO)];
     rows[(first + row) * stride + c] = v;
   }
 }
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_sample(const float *__restrict__ rows, 
   ix = ix < 0 ? 0 : (ix >= n_rows ? n_rows - 1 : ix);
   if (idx_out && lane == 0) idx_out[b] = ix;
   const float *src = rows + ix * stride;
-  const int W = 2 * S + A + 2;
+  const int NO = round_up(S + A + 2, 4), W = NO + S;  // s' starts on a 16-byte boundary
   for (int c = lane; c < W; c += 64) {
     const float v = src[c];
     if (c < S)
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void k_sample(const float *__restrict__ rows, 
       r[b] = v;
     else if (c == S + A + 1)
       d[b] = v;
-    else
-      s2[(size_t)b * S + (c - S - A - 2)] = v;
+    else if (c >= NO)
+      s2[(size_t)b * S + (c - NO)] = v;
   }
 }
 

@@ -32,30 +32,36 @@ struct TrainNet {
   int64_t off_w[3], off_b[3];
   int64_t toff_w[3], toff_b[3];  // target arena offsets (q nets), -1 otherwise
   void *wc[3];                   // compute copies written by the update kernel
-  void *w2ct;                    // [H][H] transposed copy of layer 2 (backward)
+  void *w2ct;                    // [H][H] transposed copy of layer 2 (backward GEMM)
+  void *w3t;                     // [H][out_pad] row-major transposed copy of layer 3 (backward: one
+                                 // hidden unit's weights to all outputs are 1-2 contiguous 16-byte reads)
   void *tc[3];                   // target compute copies (q nets) or null
   int32_t in_dim, k1pad, out_dim, out_pad;
   int32_t has_target;
 };
 
+// The scalars and workspace pointers every kernel needs BEFORE its first vector load sit at the
+// front, in a few adjacent cache lines: a kernel reads them in one batch of scalar loads at its
+// top (a scalar load that misses is ~0.3-0.5 us; a chain of dependent ones was the first 1.5 us
+// of every kernel).
 struct TrainerDesc {
   int32_t S, A, H, B, BP, OUTW, k1max;  // BP: batch leading dimension (B padded to 32)
   int32_t E, ntrain, nfwd, net_v, net_a; // critics; E + 2; 2E + 3; E; E + 1
   int32_t out_v, out_qt, out_nv, out_mean;  // column bases in outs[][]
-  float two_over_B, inv_E;               // mse backward: (2/B) * (q - t) * (1/E)   (ref:606)
+  int32_t stage_stride, next_off;        // replay row stride; float offset of s' inside a row
+  int32_t opmax, xrows;
   int32_t deterministic, has_dropout;
+  int32_t prefetch;                      // k_update's idle work-groups gather the next step's batch
+  int32_t polyak_convex; // 0: t + tau (p - t) (offline/iql.py), 1: (1 - tau) t + tau p (custom_offline)
+  float two_over_B, inv_E;               // mse backward: (2/B) * (q - t) * (1/E)   (ref:606)
   float discount, tau, beta, iql_tau;
+  float one_m_tau;       // float(1 - tau) for the convex Polyak form
   float drop_scale;      // 1/(1-p), bf16-rounded in bf16 mode (ATen _dropout_impl)
   uint32_t drop_thr;     // keep iff philox word >= thr
-  double beta1, beta2, eps;
-  int64_t t_max;
+  int32_t pad0_;
   uint64_t seed;
-  // arenas
-  float *params, *exp_avg, *exp_avg_sq, *target, *grads;
-  int64_t off_log_std;
-  FwdNet fwd[MAX_FWD];
-  TrainNet net[MAX_TRAIN];
   // workspace (T = compute type)
+  float *stage_rows;  // [B][stage_stride] the batch of the step about to run (k_stage / k_update)
   void *xT;       // [xrows][B]   layer-1 input (s|a), feature-major
   float *rd;      // [B][2]       reward, done
   float *actf;    // [B][A]       actions (fp32, actor loss)
@@ -68,10 +74,14 @@ struct TrainerDesc {
   float *lossp;   // [ntrain][nslab]   per-slab loss partial sums
   float *lsp;     // [nslab][A]   per-slab d(loss)/d(std) partial sums
   float *ls_snap; // [A] log_std as of the start of the step (written by k_forward's spare block)
-  float *stage_rows;  // [B][row_stride] next step's batch, or null (no idle work-groups)
-  int32_t stage_stride;
-  int32_t opmax, xrows;
+  // arenas
+  float *params, *exp_avg, *exp_avg_sq, *target, *grads;
+  int64_t off_log_std;
   unsigned long long *dbg;  // diagnostic stamps (IQL_STAMPS builds), else null
+  double beta1, beta2, eps;
+  int64_t t_max;
+  FwdNet fwd[MAX_FWD];
+  TrainNet net[MAX_TRAIN];
 };
 
 // Host-written, read-only for the kernels during a launch sequence.
@@ -86,7 +96,6 @@ struct DevArgs {
   int64_t base_step;         // total_it of the first step of this call
   double lr_q, lr_v, lr_a_base;
   int64_t n_steps;           // steps of this call (bounds idx[] for the batch prefetch)
-  int64_t call_id;           // host counter: tags the prefetched batch with the call that made it
 };
 
 // Device-written counters / metrics.
@@ -95,14 +104,11 @@ struct AdamCoef {
 };
 
 struct DevCtr {
-  int64_t ctr[2];  // [0] steps completed (read by fwd/bwd), [1] 1-based Adam step (update)
+  int64_t ctr[2];     // [0] steps completed (read by fwd/bwd), [1] 1-based Adam step (update)
+  int64_t coef_step;  // 1-based Adam step `coef` belongs to (= ctr[0] + 1 of that forward)
+  AdamCoef coef;      // written by a spare forward block for the step in flight
   float last_losses[4];
   double loss_sum[4];
-  AdamCoef coef;   // written by a spare forward block for the step in flight
-  int64_t coef_step;  // 1-based Adam step `coef` belongs to (= ctr[0] + 1 of that forward)
-  // batch prefetch: idle work-groups of k_update gather the NEXT step's replay rows into
-  // TrainerDesc::stage_rows; k_forward uses them when the tag matches its step and call
-  int64_t staged_step, staged_call;
 };
 
 // One work-group of k_update: everything it needs, flattened (no second,
@@ -116,6 +122,7 @@ struct UpdItem {
   int32_t has_target, group;  // group: 0 q, 1 v, 2 actor (which Adam step size)
   int64_t off_w, off_b, toff_w, toff_b;
   void *wc, *tc, *w2ct;    // compute copies to refresh (w2ct: layer 2 only, else null)
+  void *w3t;               // layer 3 only: [H][Opad] transposed row-major copy, else null
   const void *Xsrc, *Zsrc; // fragment-major layer input and dZ^T of this (net, layer)
 };
 

@@ -329,6 +329,41 @@ __device__ __forceinline__ void mlp_slab(const FwdNet &N, const TrainerDesc &D, 
   STAMP(0, 5);
 }
 
+// ------------------------------------------------------------------------
+// Batch staging: the B replay rows of step `step` (ref:211-221 sample: indices from the on-device
+// Philox stream, an injected index array, or the identity for an explicit batch) are copied
+// into D.stage_rows [B][stride] -- contiguous, so k_forward's gather is a coalesced read with
+// no index arithmetic in front of it.  Done by the idle work-groups of k_update for the NEXT
+// step while the update tiles work (random HBM rows + TLB misses off the critical path), and
+// by k_stage for the first step of a call (or every step when prefetching is off).
+// 16 lanes per row, 16-byte accesses (row strides are multiples of 4 floats).
+// ------------------------------------------------------------------------
+__device__ __forceinline__ void stage_rows16(const TrainerDesc &D, const DevArgs &A, int64_t step, int row0,
+                                             int row_step, int tid) {
+  const int rr = tid >> 4, l16 = tid & 15;
+  const int B = D.B, nq = D.stage_stride >> 2;
+  for (int row = row0 + rr; row < B; row += row_step) {
+    int64_t ix;
+    if (A.idx_mode == 1)
+      ix = ldg(A.idx + (size_t)(step - A.base_step) * B + row);
+    else if (A.idx_mode == 2)
+      ix = row;
+    else
+      ix = philox_index(D.seed, (uint64_t)step, (uint32_t)row, (uint64_t)A.n_rows);
+    ix = ix < 0 ? 0 : (ix >= A.n_rows ? A.n_rows - 1 : ix);
+    const float *src = A.rows + (size_t)ix * A.row_stride;
+    float *dst = D.stage_rows + (size_t)row * D.stage_stride;
+    for (int c = l16; c < nq; c += 16) stg16(dst + 4 * c, __builtin_bit_cast(float4, ldg16(src + 4 * c)));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_stage(const TrainerDesc *__restrict__ Dp,
+                                               const DevArgs *__restrict__ Ap,
+                                               const DevCtr *__restrict__ Cp) {
+  Dp += blockIdx.y, Ap += blockIdx.y, Cp += blockIdx.y;
+  stage_rows16(*Dp, *Ap, Cp->ctr[0], blockIdx.x * 16, gridDim.x * 16, threadIdx.x);
+}
+
 __device__ __forceinline__ void write_adam_coef(const TrainerDesc &D, const DevArgs &A, int64_t t1,
                                                 AdamCoef *out);
 
@@ -393,92 +428,81 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
       stg(D.ls_snap + threadIdx.x, ldg(D.params + D.off_log_std + threadIdx.x));
     return;
   }
-  const DevArgs A = *Ap;
+  // ---- ONE batch of scalar loads: everything the load phase needs, before any branch ----
   const FwdNet N = D.fwd[fnet];
-  const int64_t step = Cp->ctr[0];
+  const int B = D.B, BP = D.BP, OUTW = D.OUTW, k1max = D.k1max;
+  const float *const stage = D.stage_rows;
+  const unsigned sstride = (unsigned)D.stage_stride;
+  const int n_act = D.A, s_dim = D.S, next_off = D.next_off;
+  float *const g_outs = D.outs;
+  void *const g_hT = D.hT, *const g_xT = D.xT;
+  float *const g_rd = D.rd, *const g_actf = D.actf;
+  const int64_t step = Cp->ctr[0];  // dropout masks only
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-uniform branches stay scalar
   const int r = lane & 15, q = lane >> 4;
-  const int K1P = D.k1max + P::EPV;
+  const int K1P = k1max + P::EPV;
   T *xs = reinterpret_cast<T *>(smem);   // [ROWS][K1P]  layer-1 input
   T *h1 = xs + ROWS * K1P;               // [ROWS][HP]   all of hidden layer 1
   T *h2 = h1 + ROWS * HP;                // [ROWS][HQP]  this part of hidden layer 2
-  const int B = D.B;
   STAMP(0, 0);
-  // everything the epilogues need from the descriptors joins the first batch of scalar loads
-  pin_s(D.hT), pin_s(D.BP), pin_s(N.train_slot), pin_s(N.dropout), pin_s(N.out_dim), pin_s(N.out_col);
-  pin_s(N.out_pad), pin_s(D.outs), pin_s(D.OUTW), pin_s(B);
 
-  // ---- the input rows first: loads return in order, so the gather must not queue behind the
-  // weight fragments requested next.  16 lanes per row: batch index (ref:211-214), then the
-  // row's input segment; MT passes of 16 rows.  Rows beyond B (B % ROWS != 0) re-read row B-1
-  // and are never stored.
+  // ---- the input rows first (loads return in order): the staged batch, 16 lanes per row,
+  // lane l16 takes columns 4 l16 .. +3 and 64 + 4 l16 .. +3 of its row's input segment as two
+  // 16-byte loads (segments start on 16-byte boundaries: in_off is 0 or next_off).  Clamped,
+  // never branching: columns beyond the segment re-read its last 16 bytes and are zeroed at use.
+  // The staging evaluation (q1, input s|a) also picks r and d up: they follow a in the row.
   const int rr = tid >> 4, l16 = tid & 15;
-  constexpr int NXV = 8;  // k1pad <= 128 -> at most 8 elements per lane
-  float xv[MT][NXV], av[MT][2], rdv[MT];
-  // rows already gathered by the previous k_update's idle work-groups?
-  const bool staged = D.stage_rows && Cp->staged_step == step && Cp->staged_call == A.call_id;
+  const int lim4 = (N.stage ? next_off : round_up(N.in_dim, 4)) - 4;  // last valid 16-byte column group
+  float4 xq[MT][2];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int row_ = slab * ROWS + 16 * m + rr;
-    const int row = row_ < B ? row_ : B - 1;
-    const float *src;
-    if (staged) {
-      src = D.stage_rows + (size_t)row * D.stage_stride;
-    } else {
-      int64_t ix;
-      if (A.idx_mode == 1)
-        ix = ldg(A.idx + (size_t)(step - A.base_step) * B + row);
-      else if (A.idx_mode == 2)
-        ix = row;
-      else
-        ix = philox_index(D.seed, (uint64_t)step, (uint32_t)row, (uint64_t)A.n_rows);
-      ix = ix < 0 ? 0 : (ix >= A.n_rows ? A.n_rows - 1 : ix);
-      src = A.rows + (size_t)ix * A.row_stride;
-    }
-    // unconditional loads from clamped columns (a lane-dependent `c < in_dim ? load : 0` becomes
-    // one branch per load, each followed by s_waitcnt vmcnt(0): eight serial memory latencies);
-    // the padding is zeroed when the values are used
+    const unsigned row = (unsigned)(row_ < B ? row_ : B - 1);
+    const float *src = stage + N.in_off;
 #pragma unroll
-    for (int j = 0; j < NXV; ++j) {
-      const int c = l16 + 16 * j;
-      xv[m][j] = ldg(src + N.in_off + (c < N.in_dim ? c : N.in_dim - 1));
-    }
-    rdv[m] = 0.f, av[m][0] = av[m][1] = 0.f;
-    if (N.stage) {
-      rdv[m] = ldg(src + D.S + D.A + (l16 & 1));
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int c = l16 + 16 * j;
-        av[m][j] = ldg(src + D.S + (c < D.A ? c : D.A - 1));
-      }
+    for (int j = 0; j < 2; ++j) {
+      const int c = 4 * l16 + 64 * j;
+      xq[m][j] = __builtin_bit_cast(float4, ldg16(src + (row * sstride + (unsigned)(c < lim4 ? c : lim4))));
     }
   }
   // ---- request every weight fragment this wave will need, biases first: they are needed at
-  // the END of a layer and loads return in order ----
+  // the END of a layer and loads return in order.  Uniform (SGPR) bases + one per-lane offset. ----
   const int nk1 = N.k1pad / P::KM;
   const int nt3 = N.out_pad / 16;  // 1 or 2
   const int tile2 = part * 4 + wave;  // this wave's n-tile of layer 2 (of H / 16)
   float bias1[TPW], bias3[2];
+  {
+    const float *b1w = N.b1 + 16 * (wave * TPW);
 #pragma unroll
-  for (int jj = 0; jj < TPW; ++jj) bias1[jj] = ldg(N.b1 + 16 * (wave * TPW + jj) + r);
+    for (int jj = 0; jj < TPW; ++jj) bias1[jj] = ldg(b1w + 16 * jj + r);
+  }
   const float bias2 = ldg(N.b2 + 16 * tile2 + r);
 #pragma unroll
   for (int jt = 0; jt < 2; ++jt)  // clamped (used for col < out_dim)
     bias3[jt] = ldg(N.b3 + (16 * jt + r < N.out_dim ? 16 * jt + r : N.out_dim - 1));
   uint4 w1[C::NK1][TPW], w2[C::NK2], w3[C::NK3][2];
-  const T *W1 = reinterpret_cast<const T *>(N.w1c);
-  const T *W2 = reinterpret_cast<const T *>(N.w2c);
-  const T *W3 = reinterpret_cast<const T *>(N.w3c);
-  load_w<P, C::NK1, TPW>(w1, W1, nk1, 0, nk1, wave * TPW, lane);
+  {
+    // k-steps beyond nk1 re-read the last one (no branch in the load stream); only the MFMA is guarded
+    const T *W1w = reinterpret_cast<const T *>(N.w1c) + (size_t)(wave * TPW) * nk1 * 64 * P::EPV;
 #pragma unroll
-  for (int ks = 0; ks < C::NK2; ++ks) w2[ks] = ldg16(W2 + frag_off<P>(tile2, ks, C::NK2, lane));
+    for (int ks = 0; ks < C::NK1; ++ks) {
+      const int kc = ks < nk1 ? ks : nk1 - 1;
 #pragma unroll
-  for (int ks = 0; ks < C::NK3; ++ks)
+      for (int jj = 0; jj < TPW; ++jj)
+        w1[ks][jj] = ldg16(W1w + (size_t)(jj * nk1 + kc) * 64 * P::EPV + lane * P::EPV);
+    }
+    const T *W2w = reinterpret_cast<const T *>(N.w2c) + (size_t)tile2 * C::NK2 * 64 * P::EPV;
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)  // unconditional (clamped): no branch, no drain of the queue
-      w3[ks][jt] = ldg16(W3 + frag_off<P>(jt < nt3 ? jt : 0, part * C::NK3 + ks, C::NK2, lane));
+    for (int ks = 0; ks < C::NK2; ++ks) w2[ks] = ldg16(W2w + ks * 64 * P::EPV + lane * P::EPV);
+    const T *W3w = reinterpret_cast<const T *>(N.w3c) + (size_t)(part * C::NK3) * 64 * P::EPV;
+#pragma unroll
+    for (int ks = 0; ks < C::NK3; ++ks)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)  // unconditional (clamped): no branch, no drain of the queue
+        w3[ks][jt] = ldg16(W3w + (size_t)((jt < nt3 ? jt : 0) * C::NK2 + ks) * 64 * P::EPV + lane * P::EPV);
+  }
   STAMP(0, 1);
 
   // ---- layer-1 input into LDS (+ the batch staging for k_update: evaluation 0, part 0) ----
@@ -487,19 +511,37 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
     const int row = slab * ROWS + 16 * m + rr;
     const bool st = N.stage && part == 0 && row < B;
 #pragma unroll
-    for (int j = 0; j < NXV; ++j) {
-      const int c = l16 + 16 * j;
+    for (int j = 0; j < 2; ++j) {
+      const int c = 4 * l16 + 64 * j;
+      const float v[4] = {xq[m][j].x, xq[m][j].y, xq[m][j].z, xq[m][j].w};
       if (c < N.k1pad) {
-        const T tv = P::from_f32(c < N.in_dim ? xv[m][j] : 0.f);
-        xs[(16 * m + rr) * K1P + c] = tv;
-        if (st && c < N.in_dim) stg(reinterpret_cast<T *>(D.xT) + fidx<P>(c, row, D.BP / P::KM), tv);
-      }
-    }
-    if (st) {
-      if (l16 < 2) stg(D.rd + (size_t)row * 2 + l16, rdv[m]);
+        T tv[4];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        if (l16 + 16 * j < D.A) stg(D.actf + (size_t)row * D.A + l16 + 16 * j, av[m][j]);
+        for (int e = 0; e < 4; ++e) tv[e] = P::from_f32(c + e < N.in_dim ? v[e] : 0.f);
+        if constexpr (BF16) {
+          uint2 u;
+          u.x = (uint32_t)tv[0] | ((uint32_t)tv[1] << 16), u.y = (uint32_t)tv[2] | ((uint32_t)tv[3] << 16);
+          *reinterpret_cast<uint2 *>(xs + (16 * m + rr) * K1P + c) = u;
+        } else {
+          *reinterpret_cast<float4 *>(xs + (16 * m + rr) * K1P + c) = make_float4(tv[0], tv[1], tv[2], tv[3]);
+        }
+        if (st) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c + e < N.in_dim) stg(reinterpret_cast<T *>(g_xT) + fidx<P>(c + e, row, BP / P::KM), tv[e]);
+        }
+      }
+      if (st) {  // columns [S, S + A) are the action, S + A the reward, S + A + 1 the done flag
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int col = c + e;
+          if (col <= lim4 + 3) {  // (clamped lanes hold re-read data)
+            if (col >= s_dim && col < s_dim + n_act) stg(g_actf + (size_t)row * n_act + (col - s_dim), v[e]);
+            if (col >= s_dim + n_act && col < s_dim + n_act + 2)
+              stg(g_rd + (size_t)row * 2 + (col - s_dim - n_act), v[e]);
+          }
+        }
+      }
     }
   }
   __syncthreads();
@@ -538,15 +580,15 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
         for (int i = 0; i < 4; ++i) v[i] = fmaxf(P::round(acc[m][jj][i] + bias), 0.f);
         if (N.dropout) {
           bool keep[4];
-          dropout_keep4(D, A, step, 0, (row0 >> 2) + q, col, keep);
+          dropout_keep4(D, *Ap, step, 0, (row0 >> 2) + q, col, keep);
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] = keep[i] ? P::round(v[i] * D.drop_scale) : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) h1[(16 * m + 4 * q + i) * HP + col] = P::from_f32(v[i]);
         if (mine && row0 < B)
-          store4T<BF16>(reinterpret_cast<T *>(D.hT) + (size_t)(N.train_slot * 2 + 0) * H * D.BP +
-                            fidx<P>(col, row0 + 4 * q, D.BP / P::KM), v);
+          store4T<BF16>(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 0) * H * BP +
+                            fidx<P>(col, row0 + 4 * q, BP / P::KM), v);
       }
     }
   }
@@ -576,15 +618,15 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
       for (int i = 0; i < 4; ++i) v[i] = fmaxf(P::round(acc[m][i] + bias), 0.f);
       if (N.dropout) {
         bool keep[4];
-        dropout_keep4(D, A, step, 1, (row0 >> 2) + q, col, keep);
+        dropout_keep4(D, *Ap, step, 1, (row0 >> 2) + q, col, keep);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = keep[i] ? P::round(v[i] * D.drop_scale) : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) h2[(16 * m + 4 * q + i) * HQP + 16 * wave + r] = P::from_f32(v[i]);
       if (N.train_slot >= 0 && row0 < B)
-        store4T<BF16>(reinterpret_cast<T *>(D.hT) + (size_t)(N.train_slot * 2 + 1) * H * D.BP +
-                          fidx<P>(col, row0 + 4 * q, D.BP / P::KM), v);
+        store4T<BF16>(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP +
+                          fidx<P>(col, row0 + 4 * q, BP / P::KM), v);
     }
   }
   __syncthreads();
@@ -602,7 +644,7 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
       for (int jt = 0; jt < 2; ++jt)
         if (jt < nt3) P::mma(a, w3[ks][jt], acc3[jt]);
     }
-    float *outp = D.outs + (size_t)part * B * D.OUTW;
+    float *outp = g_outs + (size_t)part * B * OUTW;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       const int col = 16 * jt + r;
@@ -611,7 +653,7 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = slab * ROWS + 16 * m + 4 * q + i;
-          if (row < B) stg(outp + (size_t)row * D.OUTW + N.out_col + col, acc3[jt][i] + bias);
+          if (row < B) stg(outp + (size_t)row * OUTW + N.out_col + col, acc3[jt][i] + bias);
         }
       }
     }
@@ -662,28 +704,6 @@ struct LossIn {
 // under autocast) and applies the actor's tanh (ref:462-470).
 constexpr int FIN_NC = 4;   // column groups of 16: OUTW = 2E + 2 + A (rounded to 4) <= 52
 constexpr int FIN_LD = 64;  // LDS row stride of the finished outputs
-template <int SPL>
-__device__ __forceinline__ void fin_loads(const TrainerDesc &D, int b, int l16, float (&pv)[FIN_NC][SPL]) {
-#pragma unroll
-  for (int c = 0; c < FIN_NC; ++c) {
-    const int col = l16 + 16 * c;
-    const int cc = col < D.OUTW ? col : D.OUTW - 1;  // branch-free: clamped, unused beyond OUTW
-#pragma unroll
-    for (int p = 0; p < SPL; ++p) pv[c][p] = ldg(D.outs + ((size_t)p * D.B + b) * D.OUTW + cc);
-  }
-}
-template <bool BF16, int SPL>
-__device__ __forceinline__ float fin_value(const TrainerDesc &D, const float (&pv)[SPL], int col) {
-  using P = Prec<BF16>;
-  float sum = pv[0];
-#pragma unroll
-  for (int p = 1; p < SPL; ++p) sum += pv[p];
-  float v = P::round(sum);
-  const bool is_mean = col >= D.out_mean && col < D.out_mean + D.A;
-  const float t = P::round(tanhf(v));
-  return is_mean ? t : v;
-}
-
 template <bool BF16>
 __device__ __forceinline__ void loss_terms(const TrainerDesc &D, int net, const LossIn &x, float fB,
                                            float &dz3, float &lterm, float &gstd) {
@@ -761,13 +781,26 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   const int net = job / SPL;
   const int part = __builtin_amdgcn_readfirstlane(job % SPL);
   if (net >= ntrain) return;
-  const TrainNet N = D.net[net];
+  // ---- ONE batch of scalar loads: everything the load phase needs, before any branch ----
+  const int out_dim = D.net[net].out_dim, out_pad = D.net[net].out_pad;
+  const void *const p_w2ct = D.net[net].w2ct, *const p_w3t = D.net[net].w3t;
+  const int B = D.B, BP = D.BP, OUTW = D.OUTW, n_act = D.A, opmax = D.opmax;
+  const float *const g_outs = D.outs, *const g_rd = D.rd, *const g_actf = D.actf;
+  const float *const g_ls = D.deterministic ? D.actf : D.ls_snap;  // unused when deterministic
+  const T *const g_hT = reinterpret_cast<const T *>(D.hT);
+  T *const g_dz1T = reinterpret_cast<T *>(D.dz1T), *const g_dz2T = reinterpret_cast<T *>(D.dz2T);
+  T *const g_dz3T = reinterpret_cast<T *>(D.dz3T);
+  float *const g_lsp = D.lsp, *const g_lossp = D.lossp;
+  const bool drop_on = D.has_dropout && net == D.net_a;
+  const float drop_scale = D.drop_scale;
+  const bool is_gauss_actor = net == D.net_a && !D.deterministic;
+  const int out_qt = D.out_qt, out_v = D.out_v, out_nv = D.out_nv, out_mean = D.out_mean, n_crit = D.E;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-uniform branches stay scalar
   const int tile0 = part * 4 + wave;  // this wave's n-tile of dZ1 (of H / 16)
   const int r = lane & 15, q = lane >> 4;
   constexpr int HP = K::HP;
-  const int B = D.B, BP = D.BP, nkb = D.BP / P::KM;
+  const int nkb = BP / P::KM;
   const float fB = (float)B;
 
   T *dz2s = reinterpret_cast<T *>(smem);                       // [16][HP]
@@ -778,16 +811,6 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   float *fin = rowsum + SLAB;                                  // [16][FIN_LD] finished forward outputs
 
   if (blk == 0 && tid == 0) Cp->ctr[1] = Cp->ctr[0] + 1;
-  T *const g_dz1T = reinterpret_cast<T *>(D.dz1T), *const g_dz2T = reinterpret_cast<T *>(D.dz2T);
-  T *const g_dz3T = reinterpret_cast<T *>(D.dz3T);
-  float *const g_lsp = D.lsp, *const g_lossp = D.lossp;
-  const int opmax = D.opmax, n_act = D.A;
-  const bool drop_on = D.has_dropout && net == D.net_a;
-  const float drop_scale = D.drop_scale;
-  const bool is_gauss_actor = net == D.net_a && !D.deterministic;
-  pin_s(g_dz1T), pin_s(g_dz2T), pin_s(g_dz3T), pin_s(g_lsp), pin_s(g_lossp), pin_s(opmax), pin_s(n_act);
-  pin_s(drop_scale), pin_s((int)drop_on), pin_s((int)is_gauss_actor);
-  pin_s(D.out_qt), pin_s(D.out_v), pin_s(D.out_nv), pin_s(D.out_mean), pin_s(D.E), pin_s(D.OUTW);
   STAMP(1, 0);
 
   // ---- the loss inputs first: loads return in order, these must not queue behind the
@@ -795,14 +818,23 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   const int lrow = tid >> 4, lj = tid & 15;
   const int brow = slab * SLAB + lrow;
   float pv[FIN_NC][SPL];
-  fin_loads<SPL>(D, brow, lj, pv);
-  const float rew = ldg(D.rd + (size_t)brow * 2), done = ldg(D.rd + (size_t)brow * 2 + 1);
+  {
+    const float *o = g_outs + (size_t)brow * OUTW;
+#pragma unroll
+    for (int c = 0; c < FIN_NC; ++c) {
+      const int col = lj + 16 * c;
+      const unsigned cc = (unsigned)(col < OUTW ? col : OUTW - 1);  // clamped, unused beyond OUTW
+#pragma unroll
+      for (int p = 0; p < SPL; ++p) pv[c][p] = ldg(o + ((unsigned)p * (unsigned)(B * OUTW) + cc));
+    }
+  }
+  const float rew = ldg(g_rd + (size_t)brow * 2), done = ldg(g_rd + (size_t)brow * 2 + 1);
   float actv[2], lsv[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {  // outputs lj and lj + 16 (A <= 32); clamped, unused beyond A
-    const int jc = lj + 16 * h < D.A ? lj + 16 * h : D.A - 1;
-    actv[h] = ldg(D.actf + (size_t)brow * D.A + jc);
-    lsv[h] = ldg((D.deterministic ? D.actf : D.ls_snap) + jc);  // unused when deterministic
+    const int jc = lj + 16 * h < n_act ? lj + 16 * h : n_act - 1;
+    actv[h] = ldg(g_actf + (size_t)brow * n_act + jc);
+    lsv[h] = ldg(g_ls + jc);
   }
   // keep these loads AHEAD of the weight stream (the scheduler otherwise moves some of them
   // behind it, and loads return in order)
@@ -810,34 +842,46 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   // ---- request everything else that does not depend on the loss, in the order it is
   // consumed: W3 and h2 for the dZ2 phase, then this part of W2^T for the GEMM, h1 for its
   // epilogue.  All unconditional (clamped). ----
-  const T *W2T = reinterpret_cast<const T *>(N.w2ct);
-  const T *W3c = reinterpret_cast<const T *>(N.wc[2]);
   const int c2 = tid < H ? tid : H - 1;  // hidden unit this thread owns in the dZ2 phase
-  float h2v[16], w3v[32];
-#pragma unroll
-  for (int j = 0; j < 32; ++j)  // used for j < out_dim only; rows beyond out_pad re-read row 0
-    w3v[j] = P::to_f32(ldg(W3c + fidx<P>(j < N.out_pad ? j : 0, c2, K::NK2)));
+  // W3^T [H][out_pad]: this unit's weights to every output, 8 (bf16) / 4 (fp32) per 16-byte load;
+  // groups beyond out_pad re-read the first one (their products are never used)
+  constexpr int W3G = 32 / P::EPV;  // 16-byte groups covering 32 outputs
+  uint4 w3q[W3G];
   {
-    const T *h2T = reinterpret_cast<const T *>(D.hT) + (size_t)(net * 2 + 1) * H * BP;
+    const T *w3row = reinterpret_cast<const T *>(p_w3t) + (size_t)c2 * out_pad;
+#pragma unroll
+    for (int g = 0; g < W3G; ++g) w3q[g] = ldg16(w3row + (g * P::EPV < out_pad ? g * P::EPV : 0));
+  }
+  float h2v[16];
+  {
+    const T *h2T = g_hT + (size_t)(net * 2 + 1) * H * BP;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4)
       load4T<BF16>(h2T + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), &h2v[4 * g4]);
   }
   __builtin_amdgcn_sched_barrier(0);
   uint4 w2t[K::NK2];
+  {
+    const T *W2Tw = reinterpret_cast<const T *>(p_w2ct) + (size_t)tile0 * K::NK2 * 64 * P::EPV;
 #pragma unroll
-  for (int ks = 0; ks < K::NK2; ++ks) w2t[ks] = ldg16(W2T + frag_off<P>(tile0, ks, K::NK2, lane));
+    for (int ks = 0; ks < K::NK2; ++ks) w2t[ks] = ldg16(W2Tw + ks * 64 * P::EPV + lane * P::EPV);
+  }
   float h1v[4];
-  load4T<BF16>(reinterpret_cast<const T *>(D.hT) + (size_t)(net * 2 + 0) * H * BP +
-                   fidx<P>(16 * tile0 + r, slab * SLAB + 4 * q, nkb),
-               h1v);
+  load4T<BF16>(g_hT + (size_t)(net * 2 + 0) * H * BP + fidx<P>(16 * tile0 + r, slab * SLAB + 4 * q, nkb), h1v);
   STAMP(1, 1);
 
   // ---- finish the forward outputs of this slab (sum of the parts, rounding, tanh) ----
 #pragma unroll
   for (int c = 0; c < FIN_NC; ++c) {
     const int col = lj + 16 * c;
-    if (col < D.OUTW) fin[lrow * FIN_LD + col] = fin_value<BF16, SPL>(D, pv[c], col);
+    if (col < OUTW) {
+      float sum = pv[c][0];
+#pragma unroll
+      for (int p = 1; p < SPL; ++p) sum += pv[c][p];
+      const float v = P::round(sum);
+      // the actor's mean columns carry its tanh (ref:462-470), rounded like every autocast output
+      fin[lrow * FIN_LD + col] = (col >= out_mean && col < out_mean + n_act) ? P::round(tanhf(v)) : v;
+    }
   }
   __syncthreads();
 
@@ -847,18 +891,18 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     LossIn lin;
     // TwinQ.forward = min(q1, q2) of the target critics (ref:531-533, 583-584); min over all E
 #pragma unroll
-    for (int e = 0; e < MAX_CRITICS; ++e) lin.qt[e] = f[D.out_qt + (e < D.E ? e : 0)];
-    lin.vv = f[D.out_v], lin.nv = f[D.out_nv], lin.qv = f[net < D.E ? net : 0];
+    for (int e = 0; e < MAX_CRITICS; ++e) lin.qt[e] = f[out_qt + (e < n_crit ? e : 0)];
+    lin.vv = f[out_v], lin.nv = f[out_nv], lin.qv = f[net < n_crit ? net : 0];
     lin.rew = rew, lin.done = done;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int j = lj + 16 * h;
-      if (h == 0 || N.out_dim > 16) {
-        lin.mean = f[D.out_mean + (j < D.A ? j : D.A - 1)];
+      if (h == 0 || out_dim > 16) {
+        lin.mean = f[out_mean + (j < n_act ? j : n_act - 1)];
         lin.act = actv[h], lin.ls = lsv[h];
         float d3, lt, gs;
         loss_terms<BF16>(D, net, lin, fB, d3, lt, gs);
-        if (j < N.out_dim) dz3[j * SLAB + lrow] = d3, lterm[j * SLAB + lrow] = lt, gstd[j * SLAB + lrow] = gs;
+        if (j < out_dim) dz3[j * SLAB + lrow] = d3, lterm[j * SLAB + lrow] = lt, gstd[j * SLAB + lrow] = gs;
       }
     }
   }
@@ -868,7 +912,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   // per-slab partial sums in a fixed order (deterministic): rows first, then the 16 row sums
   if (tid < SLAB) {
     float s = 0.f;
-    for (int j = 0; j < N.out_dim; ++j) s += lterm[j * SLAB + tid];
+    for (int j = 0; j < out_dim; ++j) s += lterm[j * SLAB + tid];
     rowsum[tid] = s;
   }
   if (part == 0 && is_gauss_actor && tid >= 64 && tid < 64 + n_act) {
@@ -879,7 +923,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     stg(g_lsp + (size_t)slab * n_act + j, s);
   }
   // d(out), feature-major, for the layer-3 weight gradient
-  for (int e = tid; part == 0 && e < N.out_dim * SLAB; e += 256) {
+  for (int e = tid; part == 0 && e < out_dim * SLAB; e += 256) {
     const int j = e / SLAB, rr = e - j * SLAB;
     stg(g_dz3T + (size_t)net * opmax * BP + fidx<P>(j, slab * SLAB + rr, nkb),
         P::from_f32(dz3[j * SLAB + rr]));
@@ -893,12 +937,23 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     for (int rr = 0; rr < SLAB; ++rr) s[rr] = 0.f;
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-      if (j < N.out_dim) {
+      if (j < out_dim) {
+        const uint4 &g = w3q[j / P::EPV];
+        float w3j;
+        if constexpr (BF16) {
+          const uint32_t wds[4] = {g.x, g.y, g.z, g.w};
+          const uint32_t wd = wds[(j % 8) >> 1];
+          w3j = bf2f((uint16_t)((j & 1) ? (wd >> 16) : (wd & 0xffff)));
+        } else {
+          const float4 gf = __builtin_bit_cast(float4, g);
+          const float fs[4] = {gf.x, gf.y, gf.z, gf.w};
+          w3j = fs[j % 4];
+        }
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const float4 dv = *reinterpret_cast<const float4 *>(&dz3[j * SLAB + 4 * g4]);
-          s[4 * g4] += dv.x * w3v[j], s[4 * g4 + 1] += dv.y * w3v[j];
-          s[4 * g4 + 2] += dv.z * w3v[j], s[4 * g4 + 3] += dv.w * w3v[j];
+          s[4 * g4] += dv.x * w3j, s[4 * g4 + 1] += dv.y * w3j;
+          s[4 * g4 + 2] += dv.z * w3j, s[4 * g4 + 3] += dv.w * w3j;
         }
       }
     }
@@ -951,6 +1006,13 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
 // ========================================================================
 // k_update
 // ========================================================================
+// Polyak update of a target weight t towards the new weight p.  Two forms, different rounding:
+//   offline/iql.py:127-129        tp.lerp_(sp, tau)                       t + tau (p - t)
+//   custom_offline/iql.py:85-87   copy_((1 - tau) * tp + tau * sp)        (1 - tau) t + tau p
+__device__ __forceinline__ float polyak(const TrainerDesc &D, float t, float p) {
+  return D.polyak_convex ? D.one_m_tau * t + D.tau * p : t + D.tau * (p - t);
+}
+
 __device__ __forceinline__ void adam_apply(float &p, float &m, float &v, float g, const AdamCoef &c,
                                            float neg_step) {
   m = m + (g - m) * c.one_m_b1;                 // exp_avg.lerp_(grad, 1 - beta1)
@@ -1020,6 +1082,8 @@ constexpr int USR = IQL_USR;     // rows of a layer-1 strip (16 or 32)
 constexpr int UOT = USR / 16;    // out-feature tiles of a strip
 constexpr int UWPO = 4 / UOT;    // waves sharing one out-feature tile (they split the in-feature tiles)
 constexpr int UNF4 = 2;          // float4 of the strip's flat range per thread in registers
+constexpr int UPD_TILE = UTO * (UTI + 4) > USR * (UMAXI + 4) ? UTO * (UTI + 4) : USR * (UMAXI + 4);
+constexpr int UPD_LDS = UPD_TILE + USR * (UMAXI + 4);  // floats of LDS per update work-group (~18 KB)
 
 template <bool BF16>
 __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
@@ -1035,12 +1099,19 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   const int r = lane & 15, q = lane >> 4;
   const int H = D.H, B = D.B, BP = D.BP;
   const int nslab = B / SLAB;
+  // ---- ONE batch of scalar loads, before any branch: the work item (clamped for the misc
+  // block), the Adam coefficients of the step, the arena pointers ----
+  const UpdItem it = items[blk < n_items ? blk : n_items - 1];
   const int64_t t1 = Cp->coef_step;  // 1-based Adam step of this update (set by k_forward)
   const AdamCoef coef = Cp->coef;
+  float *const g_params = D.params, *const g_m = D.exp_avg, *const g_v = D.exp_avg_sq;
+  float *const g_target = D.target, *const g_grads = D.grads;
 
-  // [o][i] gradient, then new weights; sized for a layer-1 strip (64 x all in-features)
-  __shared__ __attribute__((aligned(16))) float tile[UTO * (UMAXI + 4)];
-  __shared__ __attribute__((aligned(16))) float tile2[UTO * (UMAXI + 4)];  // layer-1 strip: new targets
+  // tile: [o][i] gradient, then new weights (64 x 32 tile, or a layer-1 strip of USR rows x all
+  // in-features); tile2: a strip's new target weights.  One array: the misc block sums the loss
+  // partials in all of it (UPD_LDS floats; host check in api.hip).
+  __shared__ __attribute__((aligned(16))) float lds_upd[UPD_LDS];
+  float *const tile = lds_upd, *const tile2 = lds_upd + UPD_TILE;
   __shared__ float bgrad[UTO];
   STAMP(2, 0);
 
@@ -1088,36 +1159,17 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
         stg(lo, vl), stg(lo + 1, ql), stg(lo + 2, al);
       }
       Cp->ctr[0] = t1;
-      const bool stage_ok = D.stage_rows && A.row_stride == D.stage_stride &&
-                            (A.idx_mode == 0 || (A.idx_mode == 1 && t1 - A.base_step < A.n_steps));
-      Cp->staged_step = stage_ok ? t1 : -1;
-      Cp->staged_call = A.call_id;
     }
     STAMP(2, 4);
     return;
   }
 
-  const UpdItem it = items[blk];
-  // the batch of step t1 (0-based: the next forward) can be fetched now iff its indices are known
-  const bool can_stage = D.stage_rows && A.row_stride == D.stage_stride &&
-                         (A.idx_mode == 0 || (A.idx_mode == 1 && t1 - A.base_step < A.n_steps));
   if (it.net < 0) {
-    // padding slot of the XCD-major item table: gather the next step's replay rows while the
-    // tiles work (random HBM rows + TLB misses leave the next k_forward's critical path)
-    if (can_stage) {
-      const int rr = tid >> 4, l16 = tid & 15;
-      for (int row = it.o0 * 16 + rr; row < B; row += it.i0 * 16) {
-        int64_t ix;
-        if (A.idx_mode == 1)
-          ix = ldg(A.idx + (size_t)(t1 - A.base_step) * B + row);
-        else
-          ix = philox_index(D.seed, (uint64_t)t1, (uint32_t)row, (uint64_t)A.n_rows);
-        ix = ix < 0 ? 0 : (ix >= A.n_rows ? A.n_rows - 1 : ix);
-        const float *src = A.rows + (size_t)ix * A.row_stride;
-        float *dst = D.stage_rows + (size_t)row * D.stage_stride;
-        for (int c = l16; c < D.stage_stride; c += 16) stg(dst + c, ldg(src + c));
-      }
-    }
+    // padding slot of the XCD-major item table: gather the NEXT step's replay rows while the
+    // tiles work (random HBM rows + TLB misses leave the next k_forward's critical path); possible
+    // iff that step's indices are known
+    if (D.prefetch && (A.idx_mode == 0 || (A.idx_mode == 1 && t1 - A.base_step < A.n_steps)))
+      stage_rows16(D, A, t1, it.o0 * 16, it.i0 * 16, tid);
     return;
   }
   const int L = it.layer;
@@ -1129,7 +1181,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   const bool has_target = it.has_target != 0;
   const int nk = BP / P::KM;
   // descriptor / item fields of the Adam and store phases: fetched with the first batch
-  pin_s(D.params), pin_s(D.exp_avg), pin_s(D.exp_avg_sq), pin_s(D.target), pin_s(D.grads), pin_s(D.tau);
+  pin_s(D.tau), pin_s(D.one_m_tau), pin_s(D.polyak_convex);
   pin_s(it.off_w), pin_s(it.toff_w), pin_s(it.off_b), pin_s(it.toff_b), pin_s(it.wc), pin_s(it.tc);
   pin_s(it.w2ct), pin_s(it.Xsrc), pin_s(it.Zsrc), pin_s(Kw), pin_s(neg_step);
   pin_s(coef.one_m_b1), pin_s(coef.b2), pin_s(coef.one_m_b2), pin_s(coef.bc2_sqrt), pin_s(coef.eps);
@@ -1148,17 +1200,17 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     for (int k = 0; k < UNF4; ++k) {
       const int e4 = tid + 256 * k;
       const int ec = e4 < n4 ? e4 : n4 - 1;  // branch-free: lanes past the end re-read the last element
-      pf[k] = __builtin_bit_cast(float4, ldg16(D.params + fbase + 4 * ec));
-      mf[k] = __builtin_bit_cast(float4, ldg16(D.exp_avg + fbase + 4 * ec));
-      vf[k] = __builtin_bit_cast(float4, ldg16(D.exp_avg_sq + fbase + 4 * ec));
-      tf[k] = __builtin_bit_cast(float4, ldg16((has_target ? D.target + tbase : D.params + fbase) + 4 * ec));
+      pf[k] = __builtin_bit_cast(float4, ldg16(g_params + fbase + 4 * ec));
+      mf[k] = __builtin_bit_cast(float4, ldg16(g_m + fbase + 4 * ec));
+      vf[k] = __builtin_bit_cast(float4, ldg16(g_v + fbase + 4 * ec));
+      tf[k] = __builtin_bit_cast(float4, ldg16((has_target ? g_target + tbase : g_params + fbase) + 4 * ec));
     }
     float pb, mb, vb, tb;  // branch-free (see the tiles below)
     {
       const int ob_ = o0 + (tid & (USR - 1));  // < Odim = H always
       const int64_t eb = it.off_b + ob_;
-      pb = ldg(D.params + eb), mb = ldg(D.exp_avg + eb), vb = ldg(D.exp_avg_sq + eb);
-      tb = ldg((has_target ? D.target + it.toff_b : D.params + it.off_b) + ob_);
+      pb = ldg(g_params + eb), mb = ldg(g_m + eb), vb = ldg(g_v + eb);
+      tb = ldg((has_target ? g_target + it.toff_b : g_params + it.off_b) + ob_);
     }
     STAMP(2, 1);
     // dW1^T strip: wave w = out-feature tile (w & 1) against the in-feature tiles of parity
@@ -1261,16 +1313,16 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
         adam_apply(p[k], m[k], v[k], g[k], coef, neg_step);
         tile[ol * TLD + i] = p[k];
         if (has_target) {
-          tv[k] = tv[k] + D.tau * (p[k] - tv[k]);  // lerp_ (ref:127-129)
+          tv[k] = polyak(D, tv[k], p[k]);
           tile2[ol * TLD + i] = tv[k];
         }
         if (++i == Idim) i = 0, ++ol;
       }
-      stg16(D.params + fbase + 4 * e4, make_float4(p[0], p[1], p[2], p[3]));
-      stg16(D.exp_avg + fbase + 4 * e4, make_float4(m[0], m[1], m[2], m[3]));
-      stg16(D.exp_avg_sq + fbase + 4 * e4, make_float4(v[0], v[1], v[2], v[3]));
-      if (D.grads) stg16(D.grads + fbase + 4 * e4, make_float4(g[0], g[1], g[2], g[3]));
-      if (has_target) stg16(D.target + tbase + 4 * e4, make_float4(tv[0], tv[1], tv[2], tv[3]));
+      stg16(g_params + fbase + 4 * e4, make_float4(p[0], p[1], p[2], p[3]));
+      stg16(g_m + fbase + 4 * e4, make_float4(m[0], m[1], m[2], m[3]));
+      stg16(g_v + fbase + 4 * e4, make_float4(v[0], v[1], v[2], v[3]));
+      if (g_grads) stg16(g_grads + fbase + 4 * e4, make_float4(g[0], g[1], g[2], g[3]));
+      if (has_target) stg16(g_target + tbase + 4 * e4, make_float4(tv[0], tv[1], tv[2], tv[3]));
     };
 #pragma unroll
     for (int k = 0; k < UNF4; ++k) {
@@ -1278,18 +1330,18 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       if (e4 < n4) flat_update(e4, pf[k], mf[k], vf[k], tf[k]);
     }
     for (int e4 = tid + 256 * UNF4; e4 < n4; e4 += 256)  // wide inputs (S + A > 64): from memory
-      flat_update(e4, __builtin_bit_cast(float4, ldg16(D.params + fbase + 4 * e4)),
-                  __builtin_bit_cast(float4, ldg16(D.exp_avg + fbase + 4 * e4)),
-                  __builtin_bit_cast(float4, ldg16(D.exp_avg_sq + fbase + 4 * e4)),
-                  has_target ? __builtin_bit_cast(float4, ldg16(D.target + tbase + 4 * e4))
+      flat_update(e4, __builtin_bit_cast(float4, ldg16(g_params + fbase + 4 * e4)),
+                  __builtin_bit_cast(float4, ldg16(g_m + fbase + 4 * e4)),
+                  __builtin_bit_cast(float4, ldg16(g_v + fbase + 4 * e4)),
+                  has_target ? __builtin_bit_cast(float4, ldg16(g_target + tbase + 4 * e4))
                              : make_float4(0.f, 0.f, 0.f, 0.f));
     if (tid < USR) {
       const int64_t e = it.off_b + o0 + tid;
       const float g = P::round(bgrad[tid]);
       adam_apply(pb, mb, vb, g, coef, neg_step);
-      stg(D.params + e, pb), stg(D.exp_avg + e, mb), stg(D.exp_avg_sq + e, vb);
-      if (D.grads) stg(D.grads + e, g);
-      if (has_target) stg(D.target + it.toff_b + o0 + tid, tb + D.tau * (pb - tb));
+      stg(g_params + e, pb), stg(g_m + e, mb), stg(g_v + e, vb);
+      if (g_grads) stg(g_grads + e, g);
+      if (has_target) stg(g_target + it.toff_b + o0 + tid, polyak(D, tb, pb));
     }
     __syncthreads();
     // compute copies: 4 consecutive in-features of one row are contiguous in the fragment-major
@@ -1382,11 +1434,11 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       const int oc = o < Odim ? o : Odim - 1;
       const int64_t e = it.off_w + (int64_t)oc * Idim + i;
       const int64_t te = (has_target ? it.toff_w : it.off_w) + (int64_t)oc * Idim + i;
-      const float4 a4 = __builtin_bit_cast(float4, ldg16(D.params + e));
-      const float4 b4 = __builtin_bit_cast(float4, ldg16(D.exp_avg + e));
-      const float4 c4 = __builtin_bit_cast(float4, ldg16(D.exp_avg_sq + e));
+      const float4 a4 = __builtin_bit_cast(float4, ldg16(g_params + e));
+      const float4 b4 = __builtin_bit_cast(float4, ldg16(g_m + e));
+      const float4 c4 = __builtin_bit_cast(float4, ldg16(g_v + e));
       // no target network: a dummy read of the parameters keeps the load unconditional
-      const float4 d4 = __builtin_bit_cast(float4, ldg16((has_target ? D.target : D.params) + te));
+      const float4 d4 = __builtin_bit_cast(float4, ldg16((has_target ? g_target : g_params) + te));
       pw[ps][0] = a4.x, pw[ps][1] = a4.y, pw[ps][2] = a4.z, pw[ps][3] = a4.w;
       mw[ps][0] = b4.x, mw[ps][1] = b4.y, mw[ps][2] = b4.z, mw[ps][3] = b4.w;
       vw[ps][0] = c4.x, vw[ps][1] = c4.y, vw[ps][2] = c4.z, vw[ps][3] = c4.w;
@@ -1398,8 +1450,8 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   {
     const int ob_ = o0 + (tid & (UTO - 1)) < Odim ? o0 + (tid & (UTO - 1)) : Odim - 1;
     const int64_t eb = it.off_b + ob_;
-    pb = ldg(D.params + eb), mb = ldg(D.exp_avg + eb), vb = ldg(D.exp_avg_sq + eb);
-    tb = ldg((has_target ? D.target + it.toff_b : D.params + it.off_b) + ob_);
+    pb = ldg(g_params + eb), mb = ldg(g_m + eb), vb = ldg(g_v + eb);
+    tb = ldg((has_target ? g_target + it.toff_b : g_params + it.off_b) + ob_);
   }
   STAMP(2, 1);
 
@@ -1444,21 +1496,26 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     for (int k = 0; k < 4; ++k) {
       g[k] = P::round(g[k]);
       adam_apply(p[k], m[k], v[k], g[k], coef, neg_step);
-      if (has_target) tv[k] = tv[k] + D.tau * (p[k] - tv[k]);  // lerp_ (ref:127-129)
+      if (has_target) tv[k] = polyak(D, tv[k], p[k]);
     }
     // the new weights replace this thread's gradients in the tile (step 4 reads them transposed)
     if (L == 1) *reinterpret_cast<float4 *>(&tile[ol * ULD + tc4]) = make_float4(p[0], p[1], p[2], p[3]);
     if (o < Odim && i < Idim) {
       const int64_t e = it.off_w + (int64_t)o * Idim + i;
       const int64_t te = it.toff_w + (int64_t)o * Idim + i;
-      stg16(D.params + e, make_float4(p[0], p[1], p[2], p[3]));
-      stg16(D.exp_avg + e, make_float4(m[0], m[1], m[2], m[3]));
-      stg16(D.exp_avg_sq + e, make_float4(v[0], v[1], v[2], v[3]));
-      if (D.grads) stg16(D.grads + e, make_float4(g[0], g[1], g[2], g[3]));
-      if (has_target) stg16(D.target + te, make_float4(tv[0], tv[1], tv[2], tv[3]));
+      stg16(g_params + e, make_float4(p[0], p[1], p[2], p[3]));
+      stg16(g_m + e, make_float4(m[0], m[1], m[2], m[3]));
+      stg16(g_v + e, make_float4(v[0], v[1], v[2], v[3]));
+      if (g_grads) stg16(g_grads + e, make_float4(g[0], g[1], g[2], g[3]));
+      if (has_target) stg16(g_target + te, make_float4(tv[0], tv[1], tv[2], tv[3]));
       // 4 consecutive k of one row are contiguous in the fragment-major copies
       store4T<BF16>(wc + fidx<P>(o, i, nkw), p);
       if (has_target) store4T<BF16>(tc + fidx<P>(o, i, nkw), tv);
+      if (L == 2) {  // layer 3: the [H][Opad] transposed copy k_backward reads (one unit's weights to all outputs)
+        T *w3t = reinterpret_cast<T *>(it.w3t);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) stg(w3t + (size_t)(i + k) * Opad + o, P::from_f32(p[k]));
+      }
     }
   }
   STAMP(2, 5);
@@ -1467,9 +1524,9 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     const int64_t e = it.off_b + o0 + tid;
     const float g = P::round(bgrad[tid]);
     adam_apply(pb, mb, vb, g, coef, neg_step);
-    stg(D.params + e, pb), stg(D.exp_avg + e, mb), stg(D.exp_avg_sq + e, vb);
-    if (D.grads) stg(D.grads + e, g);
-    if (has_target) stg(D.target + it.toff_b + o0 + tid, tb + D.tau * (pb - tb));
+    stg(g_params + e, pb), stg(g_m + e, mb), stg(g_v + e, vb);
+    if (g_grads) stg(g_grads + e, g);
+    if (has_target) stg(g_target + it.toff_b + o0 + tid, polyak(D, tb, pb));
   }
   STAMP(2, 6);
   // ---- 4. transposed compute copy of layer 2 for the backward GEMM: [in][out] ----
@@ -1533,6 +1590,7 @@ __global__ void k_sync_weights(const TrainerDesc *__restrict__ Dp) {
       const float p = ldg(D.params + N.off_w[L] + e);
       stg(reinterpret_cast<T *>(N.wc[L]) + fidx<P>(o, i, Kw / P::KM), P::from_f32(p));
       if (L == 1) stg(reinterpret_cast<T *>(N.w2ct) + fidx<P>(i, o, H / P::KM), P::from_f32(p));
+      if (L == 2) stg(reinterpret_cast<T *>(N.w3t) + (size_t)i * N.out_pad + o, P::from_f32(p));
       if (N.has_target)
         stg(reinterpret_cast<T *>(N.tc[L]) + fidx<P>(o, i, Kw / P::KM),
             P::from_f32(ldg(D.target + N.toff_w[L] + e)));
@@ -1604,7 +1662,13 @@ hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *d
 #undef CALL
   return hipGetLastError();
 }
+hipError_t launch_stage(const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a, const DevCtr *c,
+                        int n_seeds, hipStream_t st) {
+  hipLaunchKernelGGL(k_stage, dim3((D.B + 15) / 16, n_seeds), dim3(256), 0, st, dD, a, c);
+  return hipGetLastError();
+}
 int strip_rows() { return USR; }
+int update_lds_floats() { return UPD_LDS; }
 hipError_t launch_update(bool bf16, const TrainerDesc *dD, const DevArgs *a, DevCtr *c,
                          const UpdItem *items, int n_items, int n_seeds, hipStream_t st) {
   // n_items tiles + the misc block; a group launch pads grid.x to a multiple of 8

@@ -273,7 +273,7 @@ __global__ void k_pack_norm(float *__restrict__ rows, int stride, int S, int A, 
                             const float *__restrict__ rew, const float *__restrict__ nxt,
                             const float *__restrict__ done, const float *__restrict__ mean,
                             const float *__restrict__ sd) {
-  const int W = 2 * S + A + 2;
+  const int NO = round_up(S + A + 2, 4), W = NO + S;  // s' starts on a 16-byte boundary
   const int64_t total = n * (int64_t)stride;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
@@ -288,8 +288,8 @@ __global__ void k_pack_norm(float *__restrict__ rows, int stride, int S, int A, 
       v = rew[row];
     else if (c == S + A + 1)
       v = done[row];
-    else if (c < W)
-      v = (nxt[row * S + (c - S - A - 2)] - mean[c - S - A - 2]) / sd[c - S - A - 2];
+    else if (c >= NO && c < W)
+      v = (nxt[row * S + (c - NO)] - mean[c - NO]) / sd[c - NO];
     rows[(first + row) * stride + c] = v;
   }
 }

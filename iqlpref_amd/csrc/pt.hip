@@ -72,6 +72,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
                                                                const float *__restrict__ act, int64_t n_rows,
                                                                const int64_t *__restrict__ win_start,
                                                                const int32_t *__restrict__ win_len,
+                                                               const int32_t *__restrict__ win_t0,
                                                                int64_t n_win, int ql, float *__restrict__ out) {
   using P = Prec<false>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
   for (int64_t win = blockIdx.x; win < n_win; win += gridDim.x) {
     const int64_t start = win_start[win];
     const int len = win_len[win];
+    const int t0 = win_t0 ? win_t0[win] : 0;  // timestep of the window's first transition
     const int T = 2 * len;
     const int nmt = (len + 15) >> 4;  // 16-token tiles per kind
     // ================= every token: embedding, LayerNorms, key / value =================
@@ -152,14 +154,14 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
       // results of those rows are dropped), inputs 16 ks + 4 q .. + 3 (clamped past D: zeroed)
       const int kr = 16 * mt + r < len ? 16 * mt + r : len - 1;
       const float *rowp = src + (size_t)(start + kr) * D;
-      // accumulators start from bias + timestep embedding of tokens 4 q + i (timestep = position
-      // in the window, ref:1281,1291)
+      // accumulators start from bias + timestep embedding of tokens 4 q + i (timestep = t0 +
+      // position in the window; t0 = 0 in ref:1281,1291, the true step in custom_offline:209)
       f32x4 x[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = 16 * mt + 4 * q + i < len ? 16 * mt + 4 * q + i : len - 1;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) x[nt][i] = ldg(W.temb + (size_t)k * E + 16 * nt + r);
+        for (int nt = 0; nt < 4; ++nt) x[nt][i] = ldg(W.temb + (size_t)(t0 + k) * E + 16 * nt + r);
       }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -324,8 +326,8 @@ size_t pt_smem_bytes(const iqlhip_pt_weights &W, int ql) {
 }
 
 hipError_t launch_pt(const iqlhip_pt_weights &W, const float *obs, const float *act, int64_t n_rows,
-                     const int64_t *win_start, const int32_t *win_len, int64_t n_win, int ql, float *out,
-                     hipStream_t st) {
+                     const int64_t *win_start, const int32_t *win_len, const int32_t *win_t0, int64_t n_win,
+                     int ql, float *out, hipStream_t st) {
   const size_t sm = pt_smem_bytes(W, ql);
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
@@ -338,7 +340,7 @@ hipError_t launch_pt(const iqlhip_pt_weights &W, const float *obs, const float *
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_pt_relabel, dim3((unsigned)grid), dim3(64 * PT_WAVES), sm, st, W, obs, act, n_rows,
-                     win_start, win_len, n_win, ql, out);
+                     win_start, win_len, win_t0, n_win, ql, out);
   return hipGetLastError();
 }
 

@@ -159,7 +159,7 @@ def set_seed(seed: int, env=None, deterministic_torch: bool = False):
 # replay buffer (ref:164-226)
 # --------------------------------------------------------------------------- #
 class ReplayBuffer:
-    """Device-resident replay buffer with packed rows [s|a|r|d|s'|pad].
+    """Device-resident replay buffer with packed rows [s|a|r|d|pad|s'|pad] (s' 16-byte aligned).
 
     ``_states`` ... ``_dones`` are strided views into the packed matrix with the
     reference's shapes.  Storage is allocated for the rows actually loaded, not
@@ -174,6 +174,7 @@ class ReplayBuffer:
         self._state_dim, self._action_dim = state_dim, action_dim
         self._device = device
         self._stride = self._lib.iqlhip_replay_row_stride(state_dim, action_dim)
+        self._next_off = self._lib.iqlhip_replay_next_offset(state_dim, action_dim)
         self._alloc(0)
         self._sample_calls = 0
         self._sample_seed = None
@@ -185,7 +186,7 @@ class ReplayBuffer:
         self._actions = self._rows[:, S:S + A]
         self._rewards = self._rows[:, S + A:S + A + 1]
         self._dones = self._rows[:, S + A + 1:S + A + 2]
-        self._next_states = self._rows[:, S + A + 2:2 * S + A + 2]
+        self._next_states = self._rows[:, self._next_off:self._next_off + S]
 
     def _to_tensor(self, data: np.ndarray) -> torch.Tensor:
         return torch.tensor(data, dtype=torch.float32, device=self._dev)

@@ -578,19 +578,25 @@ class RewardPT(nn.Module):
         return w, keep, dev
 
     def window_values(self, obs: torch.Tensor, act: torch.Tensor, win_start: torch.Tensor,
-                      win_len: torch.Tensor, query_length: int) -> torch.Tensor:
-        """value[:, 0, -1, 0] of each (start, len) window over the device arrays obs/act."""
+                      win_len: torch.Tensor, query_length: int,
+                      win_t0: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """value[:, 0, -1, 0] of each (start, len) window over the device arrays obs/act; the
+        timestep of a window's k-th transition is ``win_t0 + k`` (0 + k when None)."""
         lib = _lib.load()
         w, keep, dev = self._weights()
         obs = obs.to(torch.float32).contiguous()
         act = act.to(torch.float32).contiguous()
         win_start = win_start.to(torch.int64).contiguous()
         win_len = win_len.to(torch.int32).contiguous()
+        if win_t0 is not None:
+            win_t0 = win_t0.to(device=dev, dtype=torch.int32).contiguous()
+            if int((win_t0 + win_len).max()) > w.n_temb:
+                raise ValueError("a window's last timestep exceeds the timestep-embedding table")
         out = torch.empty(win_start.shape[0], dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             check(lib.iqlhip_pt_relabel(C.byref(w), ptr(obs), ptr(act), obs.shape[0], ptr(win_start),
-                                        ptr(win_len), win_start.shape[0], query_length, ptr(out),
-                                        stream_ptr()))
+                                        ptr(win_len), ptr(win_t0), win_start.shape[0], query_length,
+                                        ptr(out), stream_ptr()))
         del keep
         return out
 

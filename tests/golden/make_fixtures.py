@@ -472,6 +472,30 @@ def dataset_ops(ref):
     return out
 
 
+def checkpoint_compat(ref, ckpt_path):
+    """Reference-side read of a checkpoint written by OUR trainer (tools/make_checkpoint.py on the
+    GPU box; the file is our own, loaded tensors-only): ["actor"] goes into the reference's
+    GaussianPolicy with strict=False exactly as evaluation/d4rl/iql_eval_median.py:252-262 does;
+    recorded: what load_state_dict reports and the policy's eval-mode output on fixed observations."""
+    ck = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+    sd = ck["actor"]
+    s_dim = sd["net.net.0.weight"].shape[1]
+    hidden = sd["net.net.0.weight"].shape[0]
+    a_dim = sd["log_std"].shape[0]
+    actor = ref.GaussianPolicy(s_dim, a_dim, 1.0, hidden_dim=hidden, dropout=0.1)
+    res = actor.load_state_dict(sd, strict=False)
+    actor.eval()
+    obs = np.random.default_rng(11).standard_normal((33, s_dim)).astype(np.float32)
+    with torch.no_grad():
+        dist = actor(torch.from_numpy(obs))
+        act = actor.act(obs[0], "cpu")
+    return {"obs": obs, "mean": dist.mean.numpy(), "std": dist.stddev.numpy()[0], "act0": act,
+            "missing": np.asarray(list(res.missing_keys), dtype="U"),
+            "unexpected": np.asarray(list(res.unexpected_keys), dtype="U"),
+            "total_it": np.asarray(int(ck["total_it"])),
+            "keys": np.asarray(sorted(ck.keys()), dtype="U")}
+
+
 def save(name, d):
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **d)
@@ -481,9 +505,14 @@ def save(name, d):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--checkpoint-compat", default=None,
+                    help="only write checkpoint_compat.npz from this checkpoint of our trainer")
     args = ap.parse_args()
     torch.set_num_threads(1)  # fixed summation order for the captured vectors
     ref = import_reference(args.ref)
+    if args.checkpoint_compat:
+        save("checkpoint_compat.npz", checkpoint_compat(ref, args.checkpoint_compat))
+        return
 
     cfgs = {
         # antmaze hyper-parameters (configs/offline/iql/antmaze/medium_diverse_v2.yaml)

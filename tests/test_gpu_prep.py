@@ -208,5 +208,15 @@ def test_start_up_time_at_one_million_transitions():
     _diag(f"prep at N=1M: numpy + upload {t_host * 1e3:.0f} ms; device pipeline {min(times) * 1e3:.0f} ms "
           f"(runs: {[round(t * 1e3) for t in times]})")
     np.testing.assert_array_equal(b1._rewards.cpu().numpy()[:, 0], host["rewards"])
-    np.testing.assert_allclose(b1._states[:4096].cpu().numpy(), host["observations"][:4096], rtol=1e-4, atol=1e-4)
+    # At N = 1M numpy's float32 row-order sums have drifted (1e-4 relative on the mean of a
+    # zero-mean column): the device statistics (double accumulation) are checked against float64
+    # numpy, the numpy-float32 pipeline only loosely
+    m64 = ds["observations"].astype(np.float64).mean(0)
+    s64 = ds["observations"].astype(np.float64).std(0) + 1e-3
+    want = (ds["observations"][:4096] - m64.astype(np.float32)) / s64.astype(np.float32)
+    np.testing.assert_allclose(b1._states[:4096].cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+    drift = float(np.abs(b1._states[:4096].cpu().numpy() - host["observations"][:4096]).max())
+    _diag(f"prep at N=1M: max |device - numpy float32 pipeline| on normalised states {drift:.2e} "
+          f"(numpy mean drift {float(np.abs(mh - m64).max()):.2e})")
+    assert drift < 5e-3
     assert min(times) < t_host

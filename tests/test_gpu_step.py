@@ -356,23 +356,22 @@ def test_shapes_beyond_the_goldens_vs_oracle(gh, S, A, H, B, det, drop, E, mode)
                                    rtol=3e-5 if mode == "fp32" else 6e-3)
         # The GRADIENT of every step pins the backward pass (a post-Adam parameter cannot: Adam's
         # first steps are sign-like, update = lr * g / (|g| + eps), so an eps-sized gradient entry
-        # turns rounding noise into an O(lr) parameter difference).  Errors are taken relative to
-        # the largest entry of the tensor.  Two fp32 implementations that sum in different orders
-        # can disagree on the sign of a pre-activation that is zero to within rounding; that flips
-        # relu'(z) for ONE (sample, unit) pair and moves the entries it feeds by up to that sample's
-        # share of the batch sum.  So: 99.9 % of the entries at rounding level, the rest bounded by
-        # a single sample's contribution -- a mis-indexed element (error of the order of the entry
-        # itself, entries are ~0.1-1 of the maximum) still fails the second bound.
-        bulk, worst = (2e-5, 3e-2) if mode == "fp32" else (2e-2, 1e-1)
+        # turns rounding noise into an O(lr) parameter difference).  Errors are relative to the
+        # largest entry of the tensor.  fp32: every entry at summation-order noise -- unless the
+        # oracle reports a pre-activation (or an advantage) within rounding of a kink: two fp32
+        # implementations can then fall on different sides of relu'(z) for ONE (sample, unit) pair,
+        # which moves every upstream gradient by that sample's share of the batch sum (seen at
+        # B = 1024: 5e-4 of the maximum everywhere); the bound is then a few samples' share.
+        # bf16: the entries agree bit for bit except where a bf16 rounding tie flips (same effect).
         for which, mod in (("q", tr.qf), ("v", tr.vf), ("actor", tr.actor)):
+            tight = mode == "fp32" and o.last_margin[which] > 1e-5
+            bound = 5e-5 if tight else max(4.0 / B, 2e-2 if mode == "bf16" else 0.0)
             for name, p in mod.named_parameters():
                 want = o.last_grads[which][name]
-                err = np.abs(p.grad.cpu().numpy() - want).reshape(-1) / (np.abs(want).max() + 1e-30)
-                q999 = float(np.quantile(err, 0.999)) if err.size >= 2000 else float(np.sort(err)[-2:][0])
-                _diag(f"shapes S{S} A{A} H{H} B{B} E{E} {mode} step {t} grad {which}/{name}: "
-                      f"q99.9 {q999:.2e} max {err.max():.2e}")
-                assert q999 < bulk, f"step {t} grad {which}/{name}: 99.9 % quantile {q999:.3e}"
-                assert err.max() < worst, f"step {t} grad {which}/{name}: max {err.max():.3e}"
+                err = float(np.abs(p.grad.cpu().numpy() - want).max() / (np.abs(want).max() + 1e-30))
+                _diag(f"shapes S{S} A{A} H{H} B{B} E{E} {mode} step {t} grad {which}/{name}: max {err:.2e} "
+                      f"(margin {o.last_margin[which]:.1e}, bound {bound:.1e})")
+                assert err < bound, f"step {t} grad {which}/{name}: {err:.3e} (kink margin {o.last_margin[which]:.1e})"
     for name, mod, opar in (("qf", tr.qf, o.qf), ("actor", tr.actor, o.actor), ("q_target", tr.q_target, o.q_target)):
         for k, t in mod.state_dict().items():
             # With the gradients pinned above, the parameters only need the sign-like-step bound:

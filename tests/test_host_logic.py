@@ -32,8 +32,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libiqlhip.so does not export {name}"
         assert name in _lib.SYMBOLS, f"_lib.SYMBOLS lacks {name}"
     assert lib.iqlhip_abi_version() == _lib.ABI_VERSION
-    assert lib.iqlhip_replay_row_stride(29, 8) == 68
-    assert lib.iqlhip_replay_row_stride(17, 6) == 44
+    assert lib.iqlhip_replay_row_stride(29, 8) == 72 and lib.iqlhip_replay_next_offset(29, 8) == 40
+    assert lib.iqlhip_replay_row_stride(17, 6) == 48  # [17 + 6 + 2 -> 28] + 17 -> 48
 
 
 def test_arena_layout_and_step_cost_match_survey():
