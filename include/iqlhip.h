@@ -264,8 +264,9 @@ typedef struct {
   const float *weights[IQLHIP_MLP_MAX_LAYERS]; /* device fp32                      */
   const float *biases[IQLHIP_MLP_MAX_LAYERS];  /* device fp32 [out]                */
   int32_t w_in_out;   /* 0: W[out][in] (torch nn.Linear); 1: W[in][out] (x @ W)  */
-  int32_t hidden_act; /* 0 relu, 1 tanh                                          */
-  int32_t out_act;    /* 0 none, 1 tanh                                          */
+  int32_t hidden_act; /* 0 relu, 1 tanh; 8 + i: entry i of reward_models/q_mlp.py:121-130
+                         (cos, tanh, relu, softplus, sin, leaky_relu, swish, none)  */
+  int32_t out_act;    /* 0 none, 1 tanh; 8 + i as above                          */
 } iqlhip_mlp_desc;
 
 /* out[n][out_stride] (first dims[n_layers] columns) = MLP(x[n][x_stride]).  */

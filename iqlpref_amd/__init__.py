@@ -12,6 +12,6 @@ from .relabel import (  # noqa: F401,E402
     RewardMLP, RewardPT, cvar_stability_check, empirical_cvar, keep_mask_and_steps,
     load_mlp_reward_model, load_pt_reward_model, modify_reward, qlearning_dataset_bnn,
     qlearning_dataset_mr, qlearning_dataset_mr_ensemble, qlearning_dataset_pt, return_reward_range)
-from . import distributed, prep  # noqa: F401,E402
+from . import custom_offline, distributed, prep  # noqa: F401,E402
 from .multi import SeedGroup  # noqa: F401,E402
 from .train import EpisodeLedger, build_dataset, eval_actor, policy_actions, train, wrap_env  # noqa: F401,E402

@@ -16,6 +16,7 @@ MAX_CRITICS = 8
 N_TENSORS = 6 * (MAX_CRITICS + 2) + 1
 MLP_MAX_LAYERS = 8
 MAX_GROUP = 16
+ACT_FLAX_BASE = 8  # iqlhip_mlp_desc activation code 8 + i = entry i of reward_models/q_mlp.py:121-130
 ABI_VERSION = 3
 
 ERR_INVALID = -1

@@ -1007,6 +1007,8 @@ extern "C" int iqlhip_mlp_forward(const iqlhip_mlp_desc *d, const float *x, int6
       return fail(IQLHIP_ERR_UNSUPPORTED, "layer width %d outside [1, 256]", d->dims[i]);
   for (int i = 0; i < d->n_layers; ++i)
     if (!d->weights[i] || !d->biases[i]) return fail(IQLHIP_ERR_INVALID, "null weight pointer");
+  for (int a : {d->hidden_act, d->out_act})
+    if (a < 0 || (a > 1 && a < 8) || a > 15) return fail(IQLHIP_ERR_INVALID, "activation code %d", a);
   if (x_stride < d->dims[0] || out_stride < d->dims[d->n_layers])
     return fail(IQLHIP_ERR_INVALID, "stride smaller than the row width");
   HIP_TRY(launch_mlp_f32(*d, x, n, x_stride, out, out_stride, (hipStream_t)stream));

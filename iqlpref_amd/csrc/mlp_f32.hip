@@ -57,8 +57,26 @@ __global__ void k_mlp_repack(const RepackArgs R) {
   }
 }
 
-__device__ __forceinline__ float act_apply(float v, int kind) {
-  return kind == 0 ? fmaxf(v, 0.f) : tanhf(v);
+// activation codes of iqlhip_mlp_desc: 0 / 1 are the torch containers' (hidden: relu / tanh; output:
+// none / tanh); 8 + i is entry i of reward_models/q_mlp.py:121-130
+//   cos, tanh, relu, softplus, sin, leaky_relu, swish, none
+__device__ __forceinline__ float act_flax(float v, int i) {
+  switch (i) {
+    case 0: return cosf(v);
+    case 1: return tanhf(v);
+    case 2: return fmaxf(v, 0.f);
+    case 3: return fmaxf(v, 0.f) + log1pf(expf(-fabsf(v)));  // jax.nn.softplus = logaddexp(x, 0)
+    case 4: return sinf(v);
+    case 5: return v >= 0.f ? v : 0.01f * v;                  // jax.nn.leaky_relu, slope 0.01
+    case 6: return v / (1.f + expf(-v));                      // swish = x * sigmoid(x)
+    default: return v;
+  }
+}
+__device__ __forceinline__ float act_apply(float v, int kind) {  // hidden layers
+  return kind >= 8 ? act_flax(v, kind - 8) : (kind == 0 ? fmaxf(v, 0.f) : tanhf(v));
+}
+__device__ __forceinline__ float out_apply(float v, int kind) {  // output layer
+  return kind >= 8 ? act_flax(v, kind - 8) : (kind == 1 ? tanhf(v) : v);
 }
 
 __global__ __launch_bounds__(256, 2) void k_mlp_f32(const MlpArgs M, const float *__restrict__ x, int64_t n,
@@ -145,8 +163,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_f32(const MlpArgs M, const float
           if (!last) {
             buf[rr * lda + ncol] = ncol < N ? act_apply(v, M.hidden_act) : 0.f;  // zero K padding
           } else if (ncol < N && row0 + rr < n) {
-            if (M.out_act == 1) v = tanhf(v);
-            stg(out + (size_t)(row0 + rr) * out_stride + ncol, v);
+            stg(out + (size_t)(row0 + rr) * out_stride + ncol, out_apply(v, M.out_act));
           }
         }
       }

@@ -461,6 +461,8 @@ class ImplicitQLearning:
     seed       Philox key for on-device batch indices / dropout masks
                (default: ``torch.initial_seed()``).
     keep_grads also store parameter gradients into ``p.grad`` (tests).
+    polyak_form 0: ``tp.lerp_(sp, tau)`` (ref:127-129); 1: ``(1 - tau) tp + tau sp``
+               (algorithms/custom_offline/iql.py:85-87; iqlpref_amd.custom_offline sets it).
     """
 
     def __init__(self, max_action: float, actor: nn.Module, actor_optimizer: torch.optim.Optimizer,
@@ -468,7 +470,7 @@ class ImplicitQLearning:
                  v_optimizer: torch.optim.Optimizer, iql_tau: float = 0.7, beta: float = 3.0,
                  max_steps: int = 1000000, discount: float = 0.99, tau: float = 0.005,
                  device: str = "cpu", *, precision: str = "bf16", seed: Optional[int] = None,
-                 keep_grads: bool = False):
+                 keep_grads: bool = False, polyak_form: int = 0):
         self._lib = _lib.load()
         self._dev = _lib.require_gpu(device)
         if precision not in ("bf16", "fp32"):
@@ -492,6 +494,7 @@ class ImplicitQLearning:
         self._precision = PREC_BF16 if precision == "bf16" else PREC_FP32
         self._seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         self._keep_grads = keep_grads
+        self._polyak_form = int(polyak_form)
         self._handle = None
         self._handle_batch = None
         self._group_owner = None  # the SeedGroup whose device-side group holds this trainer
@@ -549,6 +552,7 @@ class ImplicitQLearning:
         c.cosine_t_max = int(self.actor_lr_schedule.T_max)
         c.seed = self._seed
         c.n_critics = self._n_critics
+        c.polyak_form = self._polyak_form
         return c
 
     def _tensor_list(self) -> List[nn.Parameter]:

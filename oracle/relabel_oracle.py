@@ -237,7 +237,7 @@ def _lin(x, p, name):
     return (x @ p[name + ".weight"].T + p[name + ".bias"]).astype(F32)
 
 
-def pt_value_last(p, states, actions, timesteps, attn_mask, num_heads=4, eps=1e-5):
+def pt_value_last(p, states, actions, timesteps, attn_mask, num_heads=4, eps=1e-5, all_positions=False):
     """value[:, 0, -1, 0] of PT.__call__ (pref_transformer.py:210-277), eval mode.
 
     states [B,QL,S], actions [B,QL,A], timesteps [B,QL] int, attn_mask [B,QL]."""
@@ -281,6 +281,8 @@ def pt_value_last(p, states, actions, timesteps, attn_mask, num_heads=4, eps=1e-
     x = _ln(x, p["gpt.layer_norm.weight"], p["gpt.layer_norm.bias"], eps)
     hidden = x.reshape(B, QL, 2, E)[:, :, 1]  # action tokens (:241-242)
     out = _lin(hidden, p, "pref_linear")
+    if all_positions:
+        return out[:, :, -1]  # value at every timestep of the window (custom_offline/iql.py:176-192)
     return out[:, -1, -1]  # value = last output column, last timestep
 
 
@@ -293,6 +295,35 @@ def qlearning_dataset_pt(dataset, p, max_episode_steps, query_length, num_heads=
     sts, acts, ts, am = pt_windows(obs, act, ep_steps, query_length, correct_window_offsets)
     r = pt_value_last(p, sts, acts, ts, am, num_heads, eps).astype(F32)
     return relabel_dataset(dataset, r, keep)
+
+
+def custom_qlearning_dataset(episodes, p, query_length, num_heads=4, eps=1e-5):
+    """algorithms/custom_offline/iql.py:158-225 (query_length > 1) with the restated PT as r_model.
+    ``episodes``: list of dicts with observations [L+1,S], actions [L,A], terminations [L].
+    Episodes no longer than the query are labelled by ONE forward over the whole episode (values
+    at every position); longer ones by that forward for the first query_length steps and then one
+    rolling window per step with the TRUE timesteps i+1-QL .. i (custom_offline:197-211)."""
+    obs, nxt, acts, rews, dones = [], [], [], [], []
+    for ep in episodes:
+        o, a = np.asarray(ep["observations"], F32), np.asarray(ep["actions"], F32)
+        L = a.shape[0]
+        if L <= query_length:
+            r = pt_value_last(p, o[:-1][None], a[None], np.arange(L)[None], np.ones((1, L), F32),
+                              num_heads, eps, all_positions=True).reshape(L)
+        else:
+            r = np.zeros(L, F32)
+            QL = query_length
+            r[:QL] = pt_value_last(p, o[:-1][:QL][None], a[:QL][None], np.arange(QL)[None],
+                                   np.ones((1, QL), F32), num_heads, eps, all_positions=True).reshape(QL)
+            for i in range(QL, L):
+                sl = slice(i - QL + 1, i + 1)
+                r[i] = pt_value_last(p, o[:-1][sl][None], a[sl][None], np.arange(i + 1 - QL, i + 1)[None],
+                                     np.ones((1, QL), F32), num_heads, eps)[0]
+        obs.append(o[:-1]), nxt.append(o[1:]), acts.append(a), rews.append(r.astype(F32))
+        dones.append(np.asarray(ep["terminations"]))
+    return {"observations": np.concatenate(obs), "actions": np.concatenate(acts),
+            "next_observations": np.concatenate(nxt), "rewards": np.concatenate(rews),
+            "terminals": np.concatenate(dones)}
 
 
 def make_pt_params(rng, state_dim, action_dim, max_episode_steps, embd=64, pref=64, inter=256, layers=1):

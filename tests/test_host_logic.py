@@ -225,3 +225,21 @@ def test_episode_ledger_matches_reference_loop(goal_env):
         assert used == used_ref
         np.testing.assert_array_equal(np.asarray(led.scores[:n_eps]), scores)
         assert led.steps_to_goal == goal
+
+
+def test_custom_offline_window_closed_form():
+    """iqlpref_amd.custom_offline.episode_windows against the rolling loop of
+    algorithms/custom_offline/iql.py:172-211 (window start, length and first TRUE timestep of every step)."""
+    from iqlpref_amd.custom_offline import episode_windows
+    for lengths, QL in (((3, 8, 9, 25, 1), 8), ((100,), 100), ((101, 2), 100), ((5, 5), 10)):
+        start, length, t0 = episode_windows(lengths, QL)
+        want, base = [], 0
+        for L in lengths:
+            for i in range(L):
+                if i < QL:          # one forward over the first min(L, QL) steps: position i sees 0..i
+                    want.append((base, i + 1, 0))
+                else:               # rolling window i+1-QL .. i with its true timesteps
+                    want.append((base + i + 1 - QL, QL, i + 1 - QL))
+            base += L
+        got = list(zip(start.tolist(), length.tolist(), t0.tolist()))
+        assert got == want
