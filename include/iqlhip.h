@@ -236,6 +236,10 @@ int iqlhip_group_train_steps(iqlhip_group *g, const iqlhip_replay_view *views, i
                              const int64_t *const *idx, const uint8_t *const *dropout_keep,
                              float *const *losses_out, int32_t graph_unroll, void *stream);
 
+/* Per-kernel HIP-event timing of a group's launches (as iqlhip_trainer_set/get_timing). */
+int iqlhip_group_set_timing(iqlhip_group *g, int32_t enable);
+int iqlhip_group_get_timing(iqlhip_group *g, double avg_ms[3], int64_t *n_launches);
+
 /* ref:639-662 train(batch) on an explicit batch of dense device tensors
  * (shapes as iqlhip_replay_sample produces them).                           */
 int iqlhip_train_batch(iqlhip_trainer *t, const float *s, const float *a, const float *r,

@@ -789,6 +789,11 @@ struct iqlhip_group {
   hipGraphExec_t gexec = nullptr;
   int graph_unroll = 0;
   hipStream_t cap_stream = nullptr;
+  // per-kernel HIP-event timing (diagnostic mode, eager launches)
+  bool timing = false;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  double t_acc[3] = {0, 0, 0}, t_empty = 0;
+  int64_t t_n = 0;
 };
 
 static bool same_shape(const iqlhip_trainer_config &a, const iqlhip_trainer_config &b) {
@@ -871,6 +876,8 @@ extern "C" int iqlhip_group_destroy(iqlhip_group *g) {
   }
   if (g->gexec) (void)hipGraphExecDestroy(g->gexec);
   if (g->cap_stream) (void)hipStreamDestroy(g->cap_stream);
+  for (auto &e : g->ev)
+    if (e) (void)hipEventDestroy(e);
   for (int k = 0; k < iqlhip_group::ARG_RING; ++k) {
     if (g->harg_ev[k]) (void)hipEventDestroy(g->harg_ev[k]);
     if (g->harg[k]) (void)hipHostFree(g->harg[k]);
@@ -935,6 +942,32 @@ extern "C" int iqlhip_group_train_steps(iqlhip_group *g, const iqlhip_replay_vie
   if (g->tr[0]->D.prefetch) HIP_TRY(launch_stage(g->tr[0]->D, g->gdesc, g->gargs, g->gctr, g->K, st));
   // ---- the steps: hipGraphs of `graph_unroll` steps, the remainder eagerly ----
   int64_t done = 0;
+  if (g->timing) {  // one event pair per kernel; diagnostic mode only
+    iqlhip_trainer *t0 = g->tr[0];
+    for (; done < n_steps; ++done) {
+      if (!t0->D.prefetch) HIP_TRY(launch_stage(t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
+      HIP_TRY(hipEventRecord(g->ev[0], st));
+      HIP_TRY(launch_forward(t0->bf16, t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
+      HIP_TRY(hipEventRecord(g->ev[1], st));
+      HIP_TRY(launch_backward(t0->bf16, t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
+      HIP_TRY(hipEventRecord(g->ev[2], st));
+      HIP_TRY(launch_update(t0->bf16, g->gdesc, g->gargs, g->gctr, g->gitems, t0->n_items, g->K, st));
+      HIP_TRY(hipEventRecord(g->ev[3], st));
+      HIP_TRY(hipEventRecord(g->ev[4], st));
+      HIP_TRY(hipEventSynchronize(g->ev[4]));
+      for (int k = 0; k < 3; ++k) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g->ev[k], g->ev[k + 1]));
+        g->t_acc[k] += ms;
+      }
+      float ems = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ems, g->ev[3], g->ev[4]));
+      g->t_empty += ems;
+      g->t_n++;
+    }
+    for (int k = 0; k < g->K; ++k) g->tr[k]->total_it += n_steps;
+    return 0;
+  }
   if (graph_unroll > 0 && n_steps >= graph_unroll) {
     if (!g->gexec || g->graph_unroll != graph_unroll) {
       if (g->gexec) {
@@ -961,6 +994,26 @@ extern "C" int iqlhip_group_train_steps(iqlhip_group *g, const iqlhip_replay_vie
   return 0;
 }
 
+
+extern "C" int iqlhip_group_set_timing(iqlhip_group *g, int32_t enable) {
+  if (!g) return fail(IQLHIP_ERR_INVALID, "null group");
+  g->timing = enable != 0;
+  g->t_acc[0] = g->t_acc[1] = g->t_acc[2] = 0, g->t_empty = 0, g->t_n = 0;
+  if (g->timing)
+    for (auto &e : g->ev)
+      if (!e) HIP_TRY(hipEventCreate(&e));
+  return 0;
+}
+
+extern "C" int iqlhip_group_get_timing(iqlhip_group *g, double avg_ms[3], int64_t *n) {
+  if (!g) return fail(IQLHIP_ERR_INVALID, "null group");
+  for (int k = 0; k < 3; ++k) {
+    const double v = g->t_n ? (g->t_acc[k] - g->t_empty) / (double)g->t_n : 0.0;
+    avg_ms[k] = v > 0 ? v : 0.0;
+  }
+  if (n) *n = g->t_n;
+  return 0;
+}
 
 extern "C" int iqlhip_forward(iqlhip_trainer *t, int32_t which, const float *s, const float *a, int64_t n,
                               float *out, void *stream) {

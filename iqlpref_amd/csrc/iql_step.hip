@@ -484,14 +484,16 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
     bias3[jt] = ldg(N.b3 + (16 * jt + r < N.out_dim ? 16 * jt + r : N.out_dim - 1));
   uint4 w1[C::NK1][TPW], w2[C::NK2], w3[C::NK3][2];
   {
-    // k-steps beyond nk1 re-read the last one (no branch in the load stream); only the MFMA is guarded
+    // (scalar guard: a CU's L1 port moves 64 B / clk, a redundant 1 KiB fragment load costs the
+    // work-group 16 cycles of it -- the load phase of this kernel is bound by exactly that)
     const T *W1w = reinterpret_cast<const T *>(N.w1c) + (size_t)(wave * TPW) * nk1 * 64 * P::EPV;
 #pragma unroll
     for (int ks = 0; ks < C::NK1; ++ks) {
-      const int kc = ks < nk1 ? ks : nk1 - 1;
+      if (ks < nk1) {
 #pragma unroll
-      for (int jj = 0; jj < TPW; ++jj)
-        w1[ks][jj] = ldg16(W1w + (size_t)(jj * nk1 + kc) * 64 * P::EPV + lane * P::EPV);
+        for (int jj = 0; jj < TPW; ++jj)
+          w1[ks][jj] = ldg16(W1w + (size_t)(jj * nk1 + ks) * 64 * P::EPV + lane * P::EPV);
+      }
     }
     const T *W2w = reinterpret_cast<const T *>(N.w2c) + (size_t)tile2 * C::NK2 * 64 * P::EPV;
 #pragma unroll
@@ -500,8 +502,8 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
 #pragma unroll
     for (int ks = 0; ks < C::NK3; ++ks)
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt)  // unconditional (clamped): no branch, no drain of the queue
-        w3[ks][jt] = ldg16(W3w + (size_t)((jt < nt3 ? jt : 0) * C::NK2 + ks) * 64 * P::EPV + lane * P::EPV);
+      for (int jt = 0; jt < 2; ++jt)
+        if (jt < nt3) w3[ks][jt] = ldg16(W3w + (size_t)(jt * C::NK2 + ks) * 64 * P::EPV + lane * P::EPV);
   }
   STAMP(0, 1);
 
@@ -843,14 +845,14 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   // consumed: W3 and h2 for the dZ2 phase, then this part of W2^T for the GEMM, h1 for its
   // epilogue.  All unconditional (clamped). ----
   const int c2 = tid < H ? tid : H - 1;  // hidden unit this thread owns in the dZ2 phase
-  // W3^T [H][out_pad]: this unit's weights to every output, 8 (bf16) / 4 (fp32) per 16-byte load;
-  // groups beyond out_pad re-read the first one (their products are never used)
+  // W3^T [H][out_pad]: this unit's weights to every output, 8 (bf16) / 4 (fp32) per 16-byte load
   constexpr int W3G = 32 / P::EPV;  // 16-byte groups covering 32 outputs
   uint4 w3q[W3G];
   {
     const T *w3row = reinterpret_cast<const T *>(p_w3t) + (size_t)c2 * out_pad;
 #pragma unroll
-    for (int g = 0; g < W3G; ++g) w3q[g] = ldg16(w3row + (g * P::EPV < out_pad ? g * P::EPV : 0));
+    for (int g = 0; g < W3G; ++g)
+      if (g * P::EPV < out_pad) w3q[g] = ldg16(w3row + g * P::EPV);  // (scalar guard: no redundant loads)
   }
   float h2v[16];
   {

@@ -158,6 +158,22 @@ class SeedGroup:
             return [torch.cat(o) for o in out]
         return None
 
+    def kernel_times(self, replay, batch_size: int, n_steps: int = 200):
+        """Average duration (us) of the forward / backward / update launches of this group
+        (mode "group"): ``n_steps`` eager steps with a HIP-event pair around every launch."""
+        if self.mode != "group":
+            raise ValueError("kernel_times needs mode='group'")
+        self._ensure_group(batch_size)
+        check(self._lib.iqlhip_group_set_timing(self._group, 1))
+        try:
+            self.train_steps(replay, n_steps, batch_size, graph_unroll=0)
+            avg, n = (C.c_double * 3)(), C.c_int64()
+            check(self._lib.iqlhip_group_get_timing(self._group, C.byref(avg), C.byref(n)))
+        finally:
+            check(self._lib.iqlhip_group_set_timing(self._group, 0))
+        return {"k_forward": avg[0] * 1e3, "k_backward": avg[1] * 1e3, "k_update": avg[2] * 1e3,
+                "launches": int(n.value)}
+
     def synchronize(self):
         for st in self._streams:
             st.synchronize()
