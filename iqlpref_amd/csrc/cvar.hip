@@ -1,12 +1,13 @@
 // CVaR over a reward-model ensemble (ref:1003-1011, ref:1185-1187):
 //   out[c] = mean of the n_tail smallest of preds[0..S)[c]
-// preds is the [S][N] prediction matrix the reference builds on the host
-// (ref:978, 2 GB at S=500, N=1M) -- here it stays in HBM and each wave selects
-// the tail of 64 columns from an LDS copy: loads are 256-byte coalesced row
-// segments, the column lives in one LDS bank per lane (conflict free), the k-th
-// smallest value is found by a 32-step bisection on the order-preserving integer
-// image of the floats (exact, no sort), and ties at the threshold are counted so
-// that the sum equals the partition-based mean up to fp32 summation order.
+// preds is the [S][N] prediction matrix the reference builds on the host (ref:978, 2 GB at
+// S=500, N=1M) -- here it stays in HBM.  One work-group (256 threads) copies COLS columns into
+// LDS as order-preserving integer keys, column-major, and L = 256 / COLS consecutive lanes share a
+// column: the n_tail-th smallest key is found by a 32-step bisection (exact, no sort) in which
+// every lane counts its quarter-rows with 16-byte LDS reads and the L counts meet in log2(L)
+// shuffles; ties at the threshold are counted, so the sum equals the partition-based mean up to
+// fp32 summation order.  HBM traffic: 4 S bytes per column, read once, in COLS * 4 byte row
+// segments.  LDS rows are padded so that 16-byte reads of neighbouring columns hit disjoint banks.
 #include "../../include/iqlhip.h"
 #include "common.h"
 
@@ -22,64 +23,85 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 }
 
 template <int COLS>
-__global__ __launch_bounds__(64) void k_cvar(const float *__restrict__ preds, int S, int64_t N, int n_tail,
-                                             float *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_cvar(const float *__restrict__ preds, int S, int64_t N, int n_tail,
+                                              int SP, float *__restrict__ out) {
+  constexpr int L = 256 / COLS;  // lanes per column
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint32_t *keys = reinterpret_cast<uint32_t *>(smem);  // [S][COLS]
-  const int lane = threadIdx.x;
+  uint32_t *keys = reinterpret_cast<uint32_t *>(smem);  // [COLS][SP], rows >= S hold 0xffffffff
+  const int tid = threadIdx.x;
   const int64_t col0 = (int64_t)blockIdx.x * COLS;
-  const bool on = lane < COLS && col0 + lane < N;
-  for (int k = 0; k < S; ++k)
-    if (lane < COLS) keys[k * COLS + lane] = on ? f2key(preds[(size_t)k * N + col0 + lane]) : 0u;
+  {
+    const int c = tid % COLS;
+    const bool on = col0 + c < N;
+    for (int k = tid / COLS; k < SP; k += L)
+      keys[c * SP + k] = (k < S && on) ? f2key(ldg(preds + (size_t)k * N + col0 + c)) : 0xffffffffu;
+  }
   __syncthreads();
-  if (!on) return;
+  const int c = tid / L, p = tid % L;
+  const uint32_t *col = keys + c * SP;
+  const int S4 = round_up(S, 4);  // (keys beyond S compare greater than every threshold below 2^32 - 1)
   // smallest key t such that #(keys <= t) >= n_tail  == the n_tail-th smallest key
   uint32_t lo = 0u, hi = 0xffffffffu;
-  while (lo < hi) {
+#pragma unroll 1
+  for (int it = 0; it < 32; ++it) {
     const uint32_t mid = lo + ((hi - lo) >> 1);
     int cnt = 0;
-    for (int k = 0; k < S; ++k) cnt += keys[k * COLS + lane] <= mid ? 1 : 0;
-    if (cnt >= n_tail)
-      hi = mid;
-    else
-      lo = mid + 1u;
+    for (int k = 4 * p; k < S4; k += 4 * L) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(col + k);
+      cnt += (v.x <= mid ? 1 : 0) + (v.y <= mid ? 1 : 0) + (v.z <= mid ? 1 : 0) + (v.w <= mid ? 1 : 0);
+    }
+#pragma unroll
+    for (int m = L >> 1; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m);
+    if (lo < hi) {
+      if (cnt >= n_tail)
+        hi = mid;
+      else
+        lo = mid + 1u;
+    }
   }
   const float thr = key2f(lo);
   float sum = 0.f;
   int less = 0;
-  for (int k = 0; k < S; ++k) {
-    const uint32_t kk = keys[k * COLS + lane];
-    if (kk < lo) {
-      sum += key2f(kk);
-      ++less;
-    }
+  for (int k = 4 * p; k < S4; k += 4 * L) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(col + k);
+    const uint32_t kk[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (kk[e] < lo) sum += key2f(kk[e]), ++less;
   }
-  sum += (float)(n_tail - less) * thr;
-  out[col0 + lane] = sum / (float)n_tail;
+#pragma unroll
+  for (int m = L >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, m), less += __shfl_xor(less, m);
+  if (p == 0 && col0 + c < N) out[col0 + c] = (sum + (float)(n_tail - less) * thr) / (float)n_tail;
+}
+
+// LDS row stride (words): >= S rounded to 4, and = 32 mod 64, so that the 16 lanes one 16-byte LDS
+// read serves at a time (two columns at L = 8) touch 64 distinct banks
+static int cvar_row_stride(int S) {
+  int sp = round_up(S, 4);
+  while (sp % 64 != 32) sp += 4;
+  return sp;
 }
 
 hipError_t launch_cvar(const float *preds, int S, int64_t N, int n_tail, float *out, hipStream_t st) {
-  // 64 columns per wave while the LDS copy fits (S <= 600), then 32, then 16
-  const int cols = S <= 600 ? 64 : (S <= 1200 ? 32 : 16);
-  const size_t sm = (size_t)S * cols * sizeof(uint32_t);
+  const int SP = cvar_row_stride(S);
+  // 32 columns per work-group while two work-groups fit a CU's LDS, else 16, else 8
+  const int cols = (size_t)32 * SP * 4 <= 80 * 1024 ? 32 : ((size_t)16 * SP * 4 <= 80 * 1024 ? 16 : 8);
+  const size_t sm = (size_t)cols * SP * sizeof(uint32_t);
   const int64_t grid = (N + cols - 1) / cols;
-  hipError_t e = hipSuccess;
-  if (cols == 64) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cvar<64>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_cvar<64>, dim3((unsigned)grid), dim3(64), sm, st, preds, S, N, n_tail, out);
-  } else if (cols == 32) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cvar<32>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_cvar<32>, dim3((unsigned)grid), dim3(64), sm, st, preds, S, N, n_tail, out);
-  } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cvar<16>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_cvar<16>, dim3((unsigned)grid), dim3(64), sm, st, preds, S, N, n_tail, out);
-  }
+#define CVAR_LAUNCH(C)                                                                                      \
+  do {                                                                                                      \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cvar<C>),                            \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
+    if (e != hipSuccess) return e;                                                                          \
+    hipLaunchKernelGGL(k_cvar<C>, dim3((unsigned)grid), dim3(256), sm, st, preds, S, N, n_tail, SP, out);    \
+  } while (0)
+  if (cols == 32)
+    CVAR_LAUNCH(32);
+  else if (cols == 16)
+    CVAR_LAUNCH(16);
+  else
+    CVAR_LAUNCH(8);
+#undef CVAR_LAUNCH
   return hipGetLastError();
 }
 

@@ -1087,7 +1087,7 @@ constexpr int UNF4 = 2;          // float4 of the strip's flat range per thread 
 constexpr int UPD_TILE = UTO * (UTI + 4) > USR * (UMAXI + 4) ? UTO * (UTI + 4) : USR * (UMAXI + 4);
 constexpr int UPD_LDS = UPD_TILE + USR * (UMAXI + 4);  // floats of LDS per update work-group (~18 KB)
 
-template <bool BF16>
+template <bool BF16, bool LAT>
 __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
                                             const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
                                             const UpdItem *__restrict__ items, int n_items,
@@ -1198,22 +1198,23 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     const int n4 = USR * Idim / 4;  // Odim = H is a multiple of 32: the strip is always 32 full rows
     const int64_t fbase = it.off_w + (int64_t)o0 * Idim, tbase = it.toff_w + (int64_t)o0 * Idim;
     float4 pf[UNF4], mf[UNF4], vf[UNF4], tf[UNF4];
-#pragma unroll
-    for (int k = 0; k < UNF4; ++k) {
-      const int e4 = tid + 256 * k;
-      const int ec = e4 < n4 ? e4 : n4 - 1;  // branch-free: lanes past the end re-read the last element
-      pf[k] = __builtin_bit_cast(float4, ldg16(g_params + fbase + 4 * ec));
-      mf[k] = __builtin_bit_cast(float4, ldg16(g_m + fbase + 4 * ec));
-      vf[k] = __builtin_bit_cast(float4, ldg16(g_v + fbase + 4 * ec));
-      tf[k] = __builtin_bit_cast(float4, ldg16((has_target ? g_target + tbase : g_params + fbase) + 4 * ec));
-    }
     float pb, mb, vb, tb;  // branch-free (see the tiles below)
-    {
+    auto load_state = [&]() {
+#pragma unroll
+      for (int k = 0; k < UNF4; ++k) {
+        const int e4 = tid + 256 * k;
+        const int ec = e4 < n4 ? e4 : n4 - 1;  // branch-free: lanes past the end re-read the last element
+        pf[k] = __builtin_bit_cast(float4, ldg16(g_params + fbase + 4 * ec));
+        mf[k] = __builtin_bit_cast(float4, ldg16(g_m + fbase + 4 * ec));
+        vf[k] = __builtin_bit_cast(float4, ldg16(g_v + fbase + 4 * ec));
+        tf[k] = __builtin_bit_cast(float4, ldg16((has_target ? g_target + tbase : g_params + fbase) + 4 * ec));
+      }
       const int ob_ = o0 + (tid & (USR - 1));  // < Odim = H always
       const int64_t eb = it.off_b + ob_;
       pb = ldg(g_params + eb), mb = ldg(g_m + eb), vb = ldg(g_v + eb);
       tb = ldg((has_target ? g_target + it.toff_b : g_params + it.off_b) + ob_);
-    }
+    };
+    if constexpr (LAT) load_state();  // (!LAT: behind the GEMM, see the tiles below)
     STAMP(2, 1);
     // dW1^T strip: wave w = out-feature tile (w & 1) against the in-feature tiles of parity
     // (w >> 1): every element is produced by one wave, k-steps in order (no cross-wave sums)
@@ -1288,6 +1289,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     chunk(0);  // straight-line first chunk: no loop pre-header to drain the state loads in
 #pragma unroll 1
     for (int k0 = UKC; k0 < nk; k0 += UKC) chunk(k0);
+    if constexpr (!LAT) load_state();
     // C/D layout: lane (r, q) of acc[tb] holds dW[o0 + 16 wo + r][16 (th + 2 tb) + 4 q + k]
 #pragma unroll
     for (int tb = 0; tb < NT; ++tb)
@@ -1425,14 +1427,15 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   // ---- 1. optimiser state, row order: thread -> (row tr + 16 pass, columns 4 tc .. +3) ----
   const int tr = tid / UTPR, tc4 = (tid % UTPR) * 4;
   float pw[UNP][4], mw[UNP][4], vw[UNP][4], tw[UNP][4];  // statically indexed only (registers)
+  float pb, mb, vb, tb;
+  auto load_state = [&]() {
 #pragma unroll
-  for (int ps = 0; ps < UNP; ++ps) {
-    const int o = o0 + tr + URPP * ps, i = i0 + tc4;
-    // Branch-free: every lane loads (rows beyond Odim -- layer 3 has 1 or A rows -- re-read the
-    // last row; their results are never stored).  A guarded load becomes a branch, and the
-    // branch a `s_waitcnt vmcnt(0)`: the loads of one tile would queue behind each other.
-    // Idim = H here: i < Idim always, and rows of the fp32 masters are 16-byte aligned.
-    {
+    for (int ps = 0; ps < UNP; ++ps) {
+      const int o = o0 + tr + URPP * ps, i = i0 + tc4;
+      // Branch-free: every lane loads (rows beyond Odim -- layer 3 has 1 or A rows -- re-read the
+      // last row; their results are never stored).  A guarded load becomes a branch, and the
+      // branch a `s_waitcnt vmcnt(0)`: the loads of one tile would queue behind each other.
+      // Idim = H here: i < Idim always, and rows of the fp32 masters are 16-byte aligned.
       const int oc = o < Odim ? o : Odim - 1;
       const int64_t e = it.off_w + (int64_t)oc * Idim + i;
       const int64_t te = (has_target ? it.toff_w : it.off_w) + (int64_t)oc * Idim + i;
@@ -1446,15 +1449,17 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       vw[ps][0] = c4.x, vw[ps][1] = c4.y, vw[ps][2] = c4.z, vw[ps][3] = c4.w;
       tw[ps][0] = d4.x, tw[ps][1] = d4.y, tw[ps][2] = d4.z, tw[ps][3] = d4.w;
     }
-  }
-  // biases: every thread loads (clamped index, dummy target), threads < 64 of the i0 = 0 tile use them
-  float pb, mb, vb, tb;
-  {
+    // biases: every thread loads (clamped index, dummy target), threads < 64 of the i0 = 0 tile use them
     const int ob_ = o0 + (tid & (UTO - 1)) < Odim ? o0 + (tid & (UTO - 1)) : Odim - 1;
     const int64_t eb = it.off_b + ob_;
     pb = ldg(g_params + eb), mb = ldg(g_m + eb), vb = ldg(g_v + eb);
     tb = ldg((has_target ? g_target + it.toff_b : g_params + it.off_b) + ob_);
-  }
+  };
+  // LAT (one seed per launch: a latency chain on an idle chip): the state is requested right
+  // behind the operand fragments, everything in flight at once.  !LAT (several seeds per launch:
+  // throughput): the state is requested only once the fragments have been consumed -- 96 fewer
+  // live VGPRs, twice the work-groups per CU, and other work-groups hide the second round trip.
+  if constexpr (LAT) load_state();
   STAMP(2, 1);
 
   __builtin_amdgcn_sched_barrier(0);
@@ -1464,6 +1469,10 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     uint4 xf[UKC], zf[UKC][2];
     load_frags(k0, xf, zf);
     mma_frags(k0, xf, zf);
+  }
+  if constexpr (!LAT) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_state();
   }
   // C/D layout: lane (r, q) of acc[b] holds dW[ob + 16 b + r][ib + 4 q + k]
 #pragma unroll
@@ -1559,15 +1568,16 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
   backward_body<BF16, H>(Dp + blockIdx.y, Cp + blockIdx.y, (int)blockIdx.x, smem, nslab, ntrain);
 }
 
-template <bool BF16>
-__global__ __launch_bounds__(256) void k_update(const TrainerDesc *__restrict__ Dp,
-                                                const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
-                                                const UpdItem *__restrict__ items, int n_items) {
+template <bool BF16, bool LAT>
+__global__ __launch_bounds__(256, LAT ? 1 : (BF16 ? 4 : 3)) void k_update(const TrainerDesc *__restrict__ Dp,
+                                                             const DevArgs *__restrict__ Ap,
+                                                             DevCtr *__restrict__ Cp,
+                                                             const UpdItem *__restrict__ items, int n_items) {
   // group launch: blockIdx.y = seed; grid.x is padded to a multiple of 8 (so that block -> XCD
   // stays blockIdx.x & 7 for every seed), the blocks behind the misc block have nothing to do
   if ((int)blockIdx.x > n_items) return;
-  update_body<BF16>(Dp + blockIdx.y, Ap + blockIdx.y, Cp + blockIdx.y, items + (size_t)blockIdx.y * n_items,
-                    n_items, (int)blockIdx.x);
+  update_body<BF16, LAT>(Dp + blockIdx.y, Ap + blockIdx.y, Cp + blockIdx.y,
+                         items + (size_t)blockIdx.y * n_items, n_items, (int)blockIdx.x);
 }
 
 // ========================================================================
@@ -1619,7 +1629,10 @@ size_t bwd_smem_bytes(bool bf16, int H) {
 }
 // batch rows per forward work-group = 16 x this (more rows per work-group = fewer re-reads of
 // the weights; fewer work-groups): 2 for the headline batch 256 (224 work-groups at E = 2)
-int fwd_row_tiles(int B) { return (B % 64 == 0 && B >= 512) ? 4 : (B % 32 == 0 ? 2 : 1); }
+// (several seeds per launch: throughput matters more than a single seed's latency -> 64 rows)
+int fwd_row_tiles(int B, int n_seeds) {
+  return (B % 64 == 0 && (B >= 512 || n_seeds > 1)) ? 4 : (B % 32 == 0 ? 2 : 1);
+}
 int layer2_parts(int H) { return H >= 256 ? 4 : H / 64; }
 
 #define DISPATCH_H(BF, HH, CALL)                 \
@@ -1637,7 +1650,7 @@ int layer2_parts(int H) { return H >= 256 ? 4 : H / 64; }
 
 hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
                           const DevCtr *c, int n_seeds, hipStream_t st) {
-  const int mt = fwd_row_tiles(D.B), nsl = (D.B + 16 * mt - 1) / (16 * mt);
+  const int mt = fwd_row_tiles(D.B, n_seeds), nsl = (D.B + 16 * mt - 1) / (16 * mt);
   // nfwd evaluations + the spare job, each nsl slabs x SPL parts
   const int grid = 8 * ((D.nfwd + 1 + 7) / 8) * nsl * layer2_parts(D.H);
   const size_t sm = fwd_smem_bytes(bf16, D.H, D.k1max, mt);
@@ -1675,10 +1688,14 @@ hipError_t launch_update(bool bf16, const TrainerDesc *dD, const DevArgs *a, Dev
                          const UpdItem *items, int n_items, int n_seeds, hipStream_t st) {
   // n_items tiles + the misc block; a group launch pads grid.x to a multiple of 8
   const dim3 grid(n_seeds > 1 ? round_up(n_items + 1, 8) : n_items + 1, n_seeds);
-  if (bf16)
-    hipLaunchKernelGGL(k_update<true>, grid, dim3(256), 0, st, dD, a, c, items, n_items);
+  if (bf16 && n_seeds > 1)
+    hipLaunchKernelGGL((k_update<true, false>), grid, dim3(256), 0, st, dD, a, c, items, n_items);
+  else if (bf16)
+    hipLaunchKernelGGL((k_update<true, true>), grid, dim3(256), 0, st, dD, a, c, items, n_items);
+  else if (n_seeds > 1)
+    hipLaunchKernelGGL((k_update<false, false>), grid, dim3(256), 0, st, dD, a, c, items, n_items);
   else
-    hipLaunchKernelGGL(k_update<false>, grid, dim3(256), 0, st, dD, a, c, items, n_items);
+    hipLaunchKernelGGL((k_update<false, true>), grid, dim3(256), 0, st, dD, a, c, items, n_items);
   return hipGetLastError();
 }
 hipError_t launch_infer(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const FwdNet &N,
