@@ -34,6 +34,8 @@
 // both operands of dW = dZ^T X are K(batch)-contiguous 16-byte fragments, and
 // the MFMA C/D layout (4 consecutive rows per lane) stores them with 8/16-byte
 // writes.
+#include <cstdlib>
+
 #include "common.h"
 #include "iql_step.h"
 
@@ -1631,6 +1633,8 @@ size_t bwd_smem_bytes(bool bf16, int H) {
 // the weights; fewer work-groups): 2 for the headline batch 256 (224 work-groups at E = 2)
 // (several seeds per launch: throughput matters more than a single seed's latency -> 64 rows)
 int fwd_row_tiles(int B, int n_seeds) {
+  static const int forced = getenv("IQLHIP_FWD_MT") ? atoi(getenv("IQLHIP_FWD_MT")) : 0;  // A/B knob
+  if ((forced == 1 || forced == 2 || forced == 4) && B % (16 * forced) == 0) return forced;
   return (B % 64 == 0 && (B >= 512 || n_seeds > 1)) ? 4 : (B % 32 == 0 ? 2 : 1);
 }
 int layer2_parts(int H) { return H >= 256 ? 4 : H / 64; }

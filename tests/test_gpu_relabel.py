@@ -205,3 +205,36 @@ def test_qlearning_dataset_pt_vs_oracle(g, correct):
     if not correct:  # kept rows / terminals exactly as the reference returned them (fake r_model golden)
         np.testing.assert_array_equal(out["observations"], g["g5/pt/ql5/observations"])
         np.testing.assert_array_equal(np.asarray(out["terminals"], np.float32), g["g5/pt/ql5/terminals"])
+
+
+def test_bnn_posterior_at_its_stated_size(tmp_path):
+    """500 posterior weight sets (bnn_n_samples = 500, the reference's default) in the
+    on-disk form of ref:905-915 -- chain files holding lists of NUMPY arrays -- through
+    qlearning_dataset_bnn, against the oracle's loop (ref:978-1011).  N is kept small here; the
+    500 x 1M case is a bench leg (tools/bench_relabel.py)."""
+    import warnings
+    import iqlpref_amd as ia
+    rng = np.random.default_rng(4)
+    S_, A_, N, NS = 11, 3, 3001, 520
+    ws = [[(rng.standard_normal(sh) * 0.4).astype(np.float32)
+           for sh in ((S_ + A_, 32), (32,), (32, 32), (32,), (32, 1), (1,))] for _ in range(NS)]
+    for c, part in enumerate((ws[:300], ws[300:])):
+        cdir = tmp_path / "sampling_f" / f"chain_{c}" / "sampled_weights"
+        os.makedirs(cdir)
+        torch.save({"sampled_weights": part}, cdir / "sampled_weights_0000000")
+    ds = {"observations": rng.standard_normal((N, S_)).astype(np.float32),
+          "actions": rng.uniform(-1, 1, (N, A_)).astype(np.float32),
+          "rewards": np.zeros(N, np.float32), "terminals": rng.uniform(size=N) < 0.01,
+          "timeouts": np.zeros(N, bool)}
+    ds["timeouts"][199::200] = True
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = ia.qlearning_dataset_bnn(FakeEnv(200), str(tmp_path), alpha=0.95, n_samples=500, device=DEV,
+                                       dataset=dict(ds))
+    # the reference's subsample of the 520 available sets (ref:929-932)
+    pick = sorted(np.random.default_rng(seed=0).choice(NS, size=500, replace=False))
+    want, _ = ro.qlearning_dataset_ensemble(dict(ds), [ws[i] for i in pick], 0.95, 200)
+    assert out["rewards"].shape == want["rewards"].shape
+    for k in want:
+        np.testing.assert_allclose(np.asarray(out[k], np.float32), np.asarray(want[k], np.float32),
+                                   rtol=2e-5, atol=2e-5, err_msg=k)

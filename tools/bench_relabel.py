@@ -99,6 +99,24 @@ def leg(device="cuda:0", n_rows=1_000_000, pt_windows=200_000, cpu=False):
                              "roofline": {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS,
                                           "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS}}
         del preds
+    # ---- f3: BNN posterior, 500 weight sets x N transitions end to end (ref:978-1011) ----
+    if n_rows >= 1_000_000:
+        S = 500
+        sets = [_reward_mlp(rng, device) for _ in range(8)]  # 8 distinct sets cycled: the work is the same
+        preds = torch.empty((S, N), device=device)
+
+        def bnn():
+            for k in range(S):
+                w_, b_ = sets[k % len(sets)]
+                preds[k] = ia.mlp_forward_f32(w_, b_, x, w_in_out=True)[:, 0]
+            return cvar_tail_mean_device(preds, max(1, int((1 - 0.95) * S)))
+        t = _timed(bnn, reps=1)
+        out["bnn_S500"] = {"workload": f"{S} posterior samples x {N} transitions + CVaR(0.95), [S, N] fp32 "
+                                       f"prediction matrix ({4.0 * S * N / 1e9:.1f} GB) resident in HBM",
+                           "ms": t * 1e3,
+                           "roofline": {"bound": "mfma", "achieved": S * flops / t / 1e12, "peak": F32_PEAK_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": S * flops / t / 1e12 / F32_PEAK_TFLOPS}}
+        del preds
     # ---- A12: preference transformer ----
     for tag, S_, A_, QL, NW in (("pt_pen_config3", 45, 24, 100, 5_000),
                                 ("pt_antmaze_correct_offsets", 29, 8, 100, pt_windows)):

@@ -29,6 +29,8 @@ print('agents', d.get('agents_per_gpu',{}).get('value'), 'ensemble', d.get('ense
     bench20)
       timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/bench20.err
       echo "bench20 rc=$?"; tail -c 1500 $OUT/bench20.json ;;
+    ckpt)
+      timeout -k 10 120 python tools/make_checkpoint.py $OUT/our_checkpoint.pt > $OUT/ckpt.log 2>&1; echo "ckpt rc=$?"; tail -2 $OUT/ckpt.log ;;
     groupscan)
       timeout -k 10 300 python tools/group_scan.py > $OUT/group_scan.txt 2>&1; echo "groupscan rc=$?"; grep -v Dataset $OUT/group_scan.txt | cut -c1-300 ;;
     profile)
