@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--ensemble-q", type=int, default=4,
                     help="extra leg (N=1 only): BASELINE configs[4], an E-critic ensemble at batch 1024 "
                          "(same antmaze shapes); 0 disables.  Reported beside `value`, never as it")
-    ap.add_argument("--agents-per-gpu", type=int, default=4,
+    ap.add_argument("--agents-per-gpu", type=int, default=8,
                     help="extra leg (N=1 only): aggregate steps/s of this many independent seeds sharing "
                          "the GPU -- the reference launcher's AGENTS_PER_GPU "
                          "(ensemble_sweeps/launch.sh:12); 0 disables.  `value` is always 1 seed per GPU")
@@ -384,18 +384,31 @@ def agents_leg(ia, torch, tr, buf, device, seed, args, unroll, bytes_step):
     """Independent seeds sharing one GPU (same dataset: a sweep varies the seed only)."""
     A_ = args.agents_per_gpu
     trs = [tr] + [build_trainer(ia, torch, device, seed + 100 + i, args.precision) for i in range(1, A_)]
-    group = ia.SeedGroup(trs)
     u = 50
+    scan = {}
+    for k_ in sorted({2, 4, A_}):  # smaller groups first, for the scaling of the aggregate with K
+        if k_ >= A_:
+            break
+        g_ = ia.SeedGroup(trs[:k_])
+        g_.train_steps(buf, 1_000, BATCH, graph_unroll=u)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        g_.train_steps(buf, 5_000, BATCH, graph_unroll=u)
+        torch.cuda.synchronize()
+        scan[str(k_)] = k_ * 5_000 / (time.perf_counter() - t1)
+        g_.close()
+    group = ia.SeedGroup(trs)
     group.train_steps(buf, 2_000, BATCH, graph_unroll=u)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    n_multi = 20_000
+    n_multi = 10_000
     group.train_steps(buf, n_multi, BATCH, graph_unroll=u)
     torch.cuda.synchronize()
     dt_m = time.perf_counter() - t1
     v = A_ * n_multi / dt_m
+    scan[str(A_)] = v
     out = {"agents": A_, "value": v, "unit": "steps/s", "steps_per_agent": n_multi,
-           "mode": getattr(group, "mode", "streams"),
+           "mode": getattr(group, "mode", "streams"), "steps_per_s_by_agents": scan,
            "roofline_step": {"bound": "hbm", "achieved": v * bytes_step / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": v * bytes_step / 1e9 / HBM_PEAK_GBS,
                              "note": "whole step: aggregate steps/s x algorithmic bytes per step"},

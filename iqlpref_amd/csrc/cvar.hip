@@ -1,9 +1,10 @@
 // CVaR over a reward-model ensemble (ref:1003-1011, ref:1185-1187):
 //   out[c] = mean of the n_tail smallest of preds[0..S)[c]
 // preds is the [S][N] prediction matrix the reference builds on the host (ref:978, 2 GB at
-// S=500, N=1M) -- here it stays in HBM.  One work-group (256 threads) copies COLS columns into
-// LDS as order-preserving integer keys, column-major, and L = 256 / COLS consecutive lanes share a
-// column: the n_tail-th smallest key is found by a 32-step bisection (exact, no sort) in which
+// S=500, N=1M) -- here it stays in HBM.  One work-group copies COLS >= 32 columns (128-byte row
+// segments: whole HBM lines) into LDS as order-preserving integer keys, column-major, and L
+// consecutive lanes share a column (L ~ S / 16: 2 lanes at S = 20, 32 lanes = 1024-thread
+// work-groups at S = 500): the n_tail-th smallest key is found by a 32-step bisection (exact, no sort) in which
 // every lane counts its quarter-rows with 16-byte LDS reads and the L counts meet in log2(L)
 // shuffles; ties at the threshold are counted, so the sum equals the partition-based mean up to
 // fp32 summation order.  HBM traffic: 4 S bytes per column, read once, in COLS * 4 byte row
@@ -22,10 +23,10 @@ __device__ __forceinline__ float key2f(uint32_t k) {
   return __builtin_bit_cast(float, u);
 }
 
-template <int COLS>
-__global__ __launch_bounds__(256) void k_cvar(const float *__restrict__ preds, int S, int64_t N, int n_tail,
-                                              int SP, float *__restrict__ out) {
-  constexpr int L = 256 / COLS;  // lanes per column
+// COLS columns per work-group, L consecutive lanes per column (COLS * L threads)
+template <int COLS, int L>
+__global__ __launch_bounds__(COLS *L) void k_cvar(const float *__restrict__ preds, int S, int64_t N,
+                                                   int n_tail, int SP, float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint32_t *keys = reinterpret_cast<uint32_t *>(smem);  // [COLS][SP], rows >= S hold 0xffffffff
   const int tid = threadIdx.x;
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void k_cvar(const float *__restrict__ preds, i
   {
     const int c = tid % COLS;
     const bool on = col0 + c < N;
-    for (int k = tid / COLS; k < SP; k += L)
+    for (int k = tid / COLS; k < SP; k += L)  // (COLS * L threads: L rows per pass)
       keys[c * SP + k] = (k < S && on) ? f2key(ldg(preds + (size_t)k * N + col0 + c)) : 0xffffffffu;
   }
   __syncthreads();
@@ -84,23 +85,29 @@ static int cvar_row_stride(int S) {
 
 hipError_t launch_cvar(const float *preds, int S, int64_t N, int n_tail, float *out, hipStream_t st) {
   const int SP = cvar_row_stride(S);
-  // 32 columns per work-group while two work-groups fit a CU's LDS, else 16, else 8
-  const int cols = (size_t)32 * SP * 4 <= 80 * 1024 ? 32 : ((size_t)16 * SP * 4 <= 80 * 1024 ? 16 : 8);
-  const size_t sm = (size_t)cols * SP * sizeof(uint32_t);
-  const int64_t grid = (N + cols - 1) / cols;
-#define CVAR_LAUNCH(C)                                                                                      \
-  do {                                                                                                      \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cvar<C>),                            \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
-    if (e != hipSuccess) return e;                                                                          \
-    hipLaunchKernelGGL(k_cvar<C>, dim3((unsigned)grid), dim3(256), sm, st, preds, S, N, n_tail, SP, out);    \
+  int L = 2;  // lanes per column: about one per 16 rows
+  while (L < 32 && L * 16 < S) L *= 2;
+#define CVAR_LAUNCH(C, LL)                                                                                   \
+  do {                                                                                                       \
+    const size_t sm = (size_t)(C) * SP * sizeof(uint32_t);                                                   \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cvar<C, LL>),                         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);               \
+    if (e != hipSuccess) return e;                                                                           \
+    hipLaunchKernelGGL((k_cvar<C, LL>), dim3((unsigned)((N + (C)-1) / (C))), dim3((C) * (LL)), sm, st, preds, S, \
+                       N, n_tail, SP, out);                                                                  \
   } while (0)
-  if (cols == 32)
-    CVAR_LAUNCH(32);
-  else if (cols == 16)
-    CVAR_LAUNCH(16);
-  else
-    CVAR_LAUNCH(8);
+  if (L == 2)
+    CVAR_LAUNCH(128, 2);
+  else if (L == 4)
+    CVAR_LAUNCH(64, 4);
+  else if (L == 8)
+    CVAR_LAUNCH(32, 8);
+  else if (L == 16)
+    CVAR_LAUNCH(32, 16);
+  else if ((size_t)32 * SP * 4 <= 160 * 1024)
+    CVAR_LAUNCH(32, 32);
+  else  // S > ~1200: the LDS image of 32 columns no longer fits, 64-byte row segments
+    CVAR_LAUNCH(16, 32);
 #undef CVAR_LAUNCH
   return hipGetLastError();
 }

@@ -108,6 +108,56 @@ __global__ __launch_bounds__(256, 2) void k_mlp_f32(const MlpArgs M, const float
     const float *Wf = M.Wf[l];
     const float *bias = M.b[l];
     const bool last = l == M.n_layers - 1;
+    if (last && ntile < 4) {
+      // ---- narrow output layer (N < 64, e.g. the reward head N = 1): with n-tiles over waves
+      // only `ntile` waves would work through all of K; instead the four waves split the k-steps,
+      // every wave accumulates all n-tiles for its share, and the partial tiles meet in LDS ----
+      f32x4 pacc[3][4];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) pacc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ks = wave; ks < nk; ks += 4) {
+        uint4 a[4], bq[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bq[t] = ldg16(Wf + frag_off<P>(t < ntile ? t : 0, ks, nk, lane));
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          a[m] = *reinterpret_cast<const uint4 *>(buf + (16 * m + r) * lda + 16 * ks + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          if (t < ntile) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) P::mma(a[m], bq[t], pacc[t][m]);
+          }
+        }
+      }
+      __syncthreads();  // the activations have been read: the buffer holds the partial tiles now
+      f32x4 *red = reinterpret_cast<f32x4 *>(buf);  // [4 waves][ntile][4 m][64 lanes]
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        if (t < ntile)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) red[((wave * ntile + t) * 4 + m) * 64 + lane] = pacc[t][m];
+      __syncthreads();
+      for (int e = tid; e < ntile * 4 * 64; e += 256) {
+        const int ln = e & 63, m = (e >> 6) & 3, t = e >> 8;
+        f32x4 sum = red[((0 * ntile + t) * 4 + m) * 64 + ln];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) sum += red[((w * ntile + t) * 4 + m) * 64 + ln];
+        const int ncol = 16 * t + (ln & 15);
+        if (ncol < N) {
+          const float bvv = ldg(bias + ncol);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int rr = 16 * m + 4 * (ln >> 4) + i;
+            if (row0 + rr < n) stg(out + (size_t)(row0 + rr) * out_stride + ncol, out_apply(sum[i] + bvv, M.out_act));
+          }
+        }
+      }
+      __syncthreads();
+      continue;
+    }
     // this wave's n-tiles: wave, wave + 4, ... (clamped copies beyond ntile are computed on a
     // valid fragment and dropped: no branches in the load stream)
     int tile[MAXT];
@@ -198,7 +248,10 @@ hipError_t launch_mlp_f32(const iqlhip_mlp_desc &d, const float *x, int64_t n, i
   M.hidden_act = d.hidden_act, M.out_act = d.out_act;
   M.lda = round_up(maxd, 16) + 4;
   hipLaunchKernelGGL(k_mlp_repack, dim3(64, d.n_layers), dim3(256), 0, st, R);
-  const size_t sm = (size_t)MROWS * M.lda * sizeof(float);
+  // the activations [64][lda], or the partial tiles of a k-split output layer (4 waves x <= 3 n-tiles)
+  size_t sm = (size_t)MROWS * M.lda * sizeof(float);
+  const int nt_last = round_up(d.dims[d.n_layers], 16) / 16;
+  if (nt_last < 4 && sm < (size_t)4 * nt_last * 4 * 64 * 16) sm = (size_t)4 * nt_last * 4 * 64 * 16;
   // (set on every call: the attribute is per device, and a process may drive several)
   e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_f32), hipFuncAttributeMaxDynamicSharedMemorySize,
                           160 * 1024);

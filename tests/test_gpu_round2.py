@@ -217,3 +217,41 @@ def test_eval_actor_with_fake_vector_env(gh, env_name, det):
     np.testing.assert_array_equal(scores, np.asarray(want_scores[:n_eps]))
     assert steps == want_steps and (len(steps) > 0) == ("antmaze" in env_name)
     assert len(made[0].actions_seen) == k  # no environment step beyond the last needed one
+
+
+# ----------------------------------------------------------------------------- #
+# checkpoint compatibility with the reference's readers (evaluation/d4rl/iql_eval_median.py:252-262):
+# tests/golden/our_checkpoint.pt was written by OUR trainer on an MI355X (tools/make_checkpoint.py);
+# tests/golden/make_fixtures.py --checkpoint-compat loaded its ["actor"] into the REFERENCE's
+# GaussianPolicy (strict=False) and recorded the policy's output -- here our actor must give the same
+# ----------------------------------------------------------------------------- #
+def test_checkpoint_read_by_the_reference_matches_our_actor():
+    import iqlpref_amd as ia
+    g = np.load(os.path.join(helpers.GOLDEN, "checkpoint_compat.npz"))
+    assert list(g["missing"]) == [] and list(g["unexpected"]) == []  # the reference found every key it wanted
+    assert sorted(g["keys"]) == ["actor", "actor_lr_schedule", "actor_optimizer", "q_optimizer", "qf",
+                                 "total_it", "v_optimizer", "vf"]  # ref:664-674
+    ck = torch.load(os.path.join(helpers.GOLDEN, "our_checkpoint.pt"), map_location="cpu", weights_only=True)
+    assert int(g["total_it"]) == ck["total_it"] == 25
+    S, A, H = ck["actor"]["net.net.0.weight"].shape[1], ck["actor"]["log_std"].shape[0], ck["actor"]["net.net.0.weight"].shape[0]
+    actor = ia.GaussianPolicy(S, A, 1.0, hidden_dim=H, dropout=0.1)
+    res = actor.load_state_dict(ck["actor"], strict=False)
+    assert not res.missing_keys and not res.unexpected_keys
+    actor = actor.to(DEV).eval()
+    obs = torch.from_numpy(g["obs"]).to(DEV)
+    dist = actor(obs)
+    np.testing.assert_allclose(dist.mean.cpu().numpy(), g["mean"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(dist.stddev.cpu().numpy()[0], g["std"], rtol=1e-6)
+    np.testing.assert_allclose(actor.act(g["obs"][0], DEV), g["act0"], rtol=0, atol=2e-6)
+    # and the whole checkpoint resumes a trainer (ref:676-688)
+    q, v = ia.TwinQ(S, 6, hidden_dim=H).to(DEV), ia.ValueFunction(S, hidden_dim=H).to(DEV)
+    a2 = ia.GaussianPolicy(S, A, 1.0, hidden_dim=H, dropout=0.1).to(DEV)
+    tr = ia.ImplicitQLearning(
+        max_action=1.0, actor=a2, actor_optimizer=torch.optim.Adam(a2.parameters(), lr=3e-4), q_network=q,
+        q_optimizer=torch.optim.Adam(q.parameters(), lr=3e-4), v_network=v,
+        v_optimizer=torch.optim.Adam(v.parameters(), lr=3e-4), iql_tau=0.8, beta=3.0, max_steps=1000, device=DEV)
+    tr.load_state_dict(ck)
+    assert tr.total_it == 25 and torch.equal(a2.log_std.cpu(), ck["actor"]["log_std"])
+    st = tr.actor_optimizer.state[a2.log_std]
+    assert float(st["step"]) == 25 and torch.equal(st["exp_avg"].cpu(),
+                                                   ck["actor_optimizer"]["state"][0]["exp_avg"])
