@@ -340,6 +340,7 @@ __device__ __forceinline__ void mlp_slab(const FwdNet &N, const TrainerDesc &D, 
 // by k_stage for the first step of a call (or every step when prefetching is off).
 // 16 lanes per row, 16-byte accesses (row strides are multiples of 4 floats).
 // ------------------------------------------------------------------------
+// (tid >> 4 rows per pass: 16 for a 256-thread work-group, 32 for k_update's 512)
 __device__ __forceinline__ void stage_rows16(const TrainerDesc &D, const DevArgs &A, int64_t step, int row0,
                                              int row_step, int tid) {
   const int rr = tid >> 4, l16 = tid & 15;
@@ -1071,12 +1072,16 @@ constexpr int UKC = 8;  // batch k-steps per register chunk in the weight-gradie
 //   4. the new weights go through LDS once more for the transposed compute copy.
 // Rows of the first layer are not 16-byte aligned (in_dim 29, 37, ...): that layer
 // uses a scalar path over the same tile.
+constexpr int UT = 512;          // threads of an update work-group: 8 waves, two per SIMD (the Adam
+                                 // phase is bound by VALU issue: one wave per SIMD used half of it)
+constexpr int UWAVES = UT / 64;
 constexpr int UTO = 64;          // tile: out-features
 constexpr int UTI = 32;          // tile: in-features
 constexpr int ULD = UTI + 4;     // LDS row stride (floats)
 constexpr int UTPR = UTI / 4;    // threads per tile row (float4 each)
-constexpr int URPP = 256 / UTPR; // rows per pass
+constexpr int URPP = UT / UTPR;  // rows per pass
 constexpr int UNP = UTO / URPP;  // passes
+constexpr int UNB = (UTO / 16) / (UWAVES / 2);  // out-feature tiles per wave in the tile GEMM
 constexpr int UMAXI = 128;       // S + A <= 128 (host check)
 constexpr int UNIT = UMAXI / 16; // in-feature tiles of a layer-1 strip, at most
 #ifndef IQL_USR
@@ -1084,8 +1089,9 @@ constexpr int UNIT = UMAXI / 16; // in-feature tiles of a layer-1 strip, at most
 #endif
 constexpr int USR = IQL_USR;     // rows of a layer-1 strip (16 or 32)
 constexpr int UOT = USR / 16;    // out-feature tiles of a strip
-constexpr int UWPO = 4 / UOT;    // waves sharing one out-feature tile (they split the in-feature tiles)
-constexpr int UNF4 = 2;          // float4 of the strip's flat range per thread in registers
+constexpr int UWPO = UWAVES / UOT;  // waves sharing one out-feature tile (they split the in-feature tiles)
+constexpr int UNF4 = (USR * UMAXI / 4 + UT - 1) / UT;  // float4 of the strip's flat range per thread
+static_assert(UNP >= 1 && UNB >= 1 && UTO % URPP == 0, "update tile geometry");
 constexpr int UPD_TILE = UTO * (UTI + 4) > USR * (UMAXI + 4) ? UTO * (UTI + 4) : USR * (UMAXI + 4);
 constexpr int UPD_LDS = UPD_TILE + USR * (UMAXI + 4);  // floats of LDS per update work-group (~18 KB)
 
@@ -1125,7 +1131,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     float *sred = tile;
     const int nt = D.ntrain;
     const int nl = nt * nslab, na = D.deterministic ? 0 : nslab * D.A;  // nl + na + nt fits the tile (host check)
-    for (int e = tid; e < nl + na; e += 256) sred[e] = e < nl ? ldg(D.lossp + e) : ldg(D.lsp + e - nl);
+    for (int e = tid; e < nl + na; e += UT) sred[e] = e < nl ? ldg(D.lossp + e) : ldg(D.lsp + e - nl);
     float ls = 0.f, pm = 0.f, pv = 0.f;
     if (!D.deterministic && tid < D.A) {
       const int64_t o = D.off_log_std + tid;
@@ -1173,7 +1179,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     // tiles work (random HBM rows + TLB misses leave the next k_forward's critical path); possible
     // iff that step's indices are known
     if (D.prefetch && (A.idx_mode == 0 || (A.idx_mode == 1 && t1 - A.base_step < A.n_steps)))
-      stage_rows16(D, A, t1, it.o0 * 16, it.i0 * 16, tid);
+      stage_rows16(D, A, t1, it.o0 * (UT / 16), it.i0 * (UT / 16), tid);
     return;
   }
   const int L = it.layer;
@@ -1204,7 +1210,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     auto load_state = [&]() {
 #pragma unroll
       for (int k = 0; k < UNF4; ++k) {
-        const int e4 = tid + 256 * k;
+        const int e4 = tid + UT * k;
         const int ec = e4 < n4 ? e4 : n4 - 1;  // branch-free: lanes past the end re-read the last element
         pf[k] = __builtin_bit_cast(float4, ldg16(g_params + fbase + 4 * ec));
         mf[k] = __builtin_bit_cast(float4, ldg16(g_m + fbase + 4 * ec));
@@ -1231,7 +1237,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     float bsum = 0.f;
     // The operand fragments of this wave's first two in-feature tiles (16-row strips: all of
     // them) are requested up front, unconditionally (clamped indices): guards only around the MFMAs.
-    constexpr int TB = 2;
+    constexpr int TB = NT < 2 ? NT : 2;
     auto chunk = [&](const int k0) {
       uint4 zf[UKC], xf[TB][UKC];
 #pragma unroll
@@ -1332,10 +1338,10 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     };
 #pragma unroll
     for (int k = 0; k < UNF4; ++k) {
-      const int e4 = tid + 256 * k;
+      const int e4 = tid + UT * k;
       if (e4 < n4) flat_update(e4, pf[k], mf[k], vf[k], tf[k]);
     }
-    for (int e4 = tid + 256 * UNF4; e4 < n4; e4 += 256)  // wide inputs (S + A > 64): from memory
+    for (int e4 = tid + UT * UNF4; e4 < n4; e4 += UT)  // (never taken: UNF4 covers S + A <= 128)
       flat_update(e4, __builtin_bit_cast(float4, ldg16(g_params + fbase + 4 * e4)),
                   __builtin_bit_cast(float4, ldg16(g_m + fbase + 4 * e4)),
                   __builtin_bit_cast(float4, ldg16(g_v + fbase + 4 * e4)),
@@ -1353,7 +1359,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     // compute copies: 4 consecutive in-features of one row are contiguous in the fragment-major
     // image (columns Idim .. Ipad of the tile hold zero gradients = the copies' zero padding)
     const int cpr = Ipad >> 2;
-    for (int e = tid; e < USR * cpr; e += 256) {
+    for (int e = tid; e < USR * cpr; e += UT) {
       const int ol = e / cpr, i = (e - ol * cpr) * 4;
       const float4 p4 = *reinterpret_cast<const float4 *>(&tile[ol * TLD + i]);
       float pv4[4] = {p4.x, p4.y, p4.z, p4.w};
@@ -1372,11 +1378,13 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   // ---- 2. dW^T tile on MFMA: A = layer input X^T, B = dZ^T (fragment-major) ----
   const T *Xsrc = reinterpret_cast<const T *>(it.Xsrc);
   const T *Zsrc = reinterpret_cast<const T *>(it.Zsrc);
-  // wave (wo, wi) = (wave >> 1, wave & 1): in-feature tile wi x out-feature tiles 2wo, 2wo+1
+  // wave (wo, wi) = (wave >> 1, wave & 1): in-feature tile wi x out-feature tiles UNB wo .. + UNB
   const int wo = wave >> 1, wi = wave & 1;
-  const int ib = i0 + 16 * wi, ob = o0 + 32 * wo;
-  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  float bsum[2] = {0.f, 0.f};
+  const int ib = i0 + 16 * wi, ob = o0 + 16 * UNB * wo;
+  f32x4 acc[UNB];
+  float bsum[UNB];
+#pragma unroll
+  for (int b = 0; b < UNB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f}, bsum[b] = 0.f;
   const bool do_bias = i0 == 0;
   const bool wave_bias = do_bias && wi == 0;
   // Branch-free operand stream: in-features always exist here (Idim = H), out-feature tiles
@@ -1384,28 +1392,28 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   // that are never stored -- and k-steps beyond nk re-read the last one and are skipped by the
   // (scalar) guard around the MFMA only.
   const int ntile_o = Opad >> 4;
-  int ot[2];
+  int ot[UNB];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) ot[b] = (ob >> 4) + b < ntile_o ? (ob >> 4) + b : ntile_o - 1;
+  for (int b = 0; b < UNB; ++b) ot[b] = (ob >> 4) + b < ntile_o ? (ob >> 4) + b : ntile_o - 1;
   // Operand fragments are requested FIRST, the optimiser state behind them: the MFMAs (and the
   // LDS hand-over to the row-ordered Adam pass) then start as soon as the fragments are in, while
   // the state is still streaming (+0.8 % measured).  First chunk straight-line: a loop
   // pre-header would drain every pending load.
-  auto load_frags = [&](const int k0, uint4(&xf)[UKC], uint4(&zf)[UKC][2]) {
+  auto load_frags = [&](const int k0, uint4(&xf)[UKC], uint4(&zf)[UKC][UNB]) {
 #pragma unroll
     for (int ks = 0; ks < UKC; ++ks) {
       const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
       xf[ks] = ldg16(Xsrc + frag_off<P>(ib >> 4, kk, nk, lane));
 #pragma unroll
-      for (int b = 0; b < 2; ++b) zf[ks][b] = ldg16(Zsrc + frag_off<P>(ot[b], kk, nk, lane));
+      for (int b = 0; b < UNB; ++b) zf[ks][b] = ldg16(Zsrc + frag_off<P>(ot[b], kk, nk, lane));
     }
   };
-  auto mma_frags = [&](const int k0, const uint4(&xf)[UKC], const uint4(&zf)[UKC][2]) {
+  auto mma_frags = [&](const int k0, const uint4(&xf)[UKC], const uint4(&zf)[UKC][UNB]) {
 #pragma unroll
     for (int ks = 0; ks < UKC; ++ks) {
       if (k0 + ks < nk) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < UNB; ++b) {
           if (wave_bias) {  // bias gradient = row sums of dZ^T (this lane: its out-feature, 1/4 of K)
             if constexpr (BF16) {
               const uint32_t w[4] = {zf[ks][b].x, zf[ks][b].y, zf[ks][b].z, zf[ks][b].w};
@@ -1422,7 +1430,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       }
     }
   };
-  uint4 xf0[UKC], zf0[UKC][2];
+  uint4 xf0[UKC], zf0[UKC][UNB];
   load_frags(0, xf0, zf0);
   __builtin_amdgcn_sched_barrier(0);
 
@@ -1468,7 +1476,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   mma_frags(0, xf0, zf0);
 #pragma unroll 1
   for (int k0 = UKC; k0 < nk; k0 += UKC) {
-    uint4 xf[UKC], zf[UKC][2];
+    uint4 xf[UKC], zf[UKC][UNB];
     load_frags(k0, xf, zf);
     mma_frags(k0, xf, zf);
   }
@@ -1478,15 +1486,15 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   }
   // C/D layout: lane (r, q) of acc[b] holds dW[ob + 16 b + r][ib + 4 q + k]
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
-    *reinterpret_cast<f32x4 *>(&tile[(32 * wo + 16 * b + r) * ULD + 16 * wi + 4 * q]) = acc[b];
+  for (int b = 0; b < UNB; ++b)
+    *reinterpret_cast<f32x4 *>(&tile[(16 * UNB * wo + 16 * b + r) * ULD + 16 * wi + 4 * q]) = acc[b];
   if (wave_bias) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < UNB; ++b) {
       float bs = bsum[b];
       bs += __shfl_xor(bs, 16);
       bs += __shfl_xor(bs, 32);
-      if (q == 0) bgrad[32 * wo + 16 * b + r] = bs;
+      if (q == 0) bgrad[16 * UNB * wo + 16 * b + r] = bs;
     }
   }
   __syncthreads();
@@ -1545,11 +1553,11 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   // ---- 4. transposed compute copy of layer 2 for the backward GEMM: [in][out] ----
   if (L == 1) {
     __syncthreads();
-    // thread -> in-feature i0 + (tid >> 4) + 16 pass, out-features o0 + 4 (tid & 15) .. +3
+    // thread -> in-feature i0 + (tid & 31), out-features o0 + 4 (tid >> 5) .. +3 (+ UT / 8 per pass)
 #pragma unroll
-    for (int ps = 0; ps < UTI / 16; ++ps) {
+    for (int ps = 0; ps < (UTO / 4) / (UT / UTI); ++ps) {
       // consecutive lanes read consecutive in-features of one tile row: conflict-free LDS reads
-      const int il = tid & (UTI - 1), o4 = ((tid >> 5) + 8 * ps) * 4;
+      const int il = tid & (UTI - 1), o4 = ((tid >> 5) + (UT / UTI) * ps) * 4;
       float pv4[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) pv4[k] = tile[(o4 + k) * ULD + il];
@@ -1571,7 +1579,7 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
 }
 
 template <bool BF16, bool LAT>
-__global__ __launch_bounds__(256, LAT ? 1 : (BF16 ? 4 : 3)) void k_update(const TrainerDesc *__restrict__ Dp,
+__global__ __launch_bounds__(UT, LAT ? 2 : (BF16 ? 4 : 3)) void k_update(const TrainerDesc *__restrict__ Dp,
                                                              const DevArgs *__restrict__ Ap,
                                                              DevCtr *__restrict__ Cp,
                                                              const UpdItem *__restrict__ items, int n_items) {
@@ -1698,13 +1706,13 @@ hipError_t launch_update(bool bf16, const TrainerDesc *dD, const DevArgs *a, Dev
   // n_items tiles + the misc block; a group launch pads grid.x to a multiple of 8
   const dim3 grid(n_seeds > 1 ? round_up(n_items + 1, 8) : n_items + 1, n_seeds);
   if (bf16 && n_seeds > 1)
-    hipLaunchKernelGGL((k_update<true, false>), grid, dim3(256), 0, st, dD, a, c, items, n_items);
+    hipLaunchKernelGGL((k_update<true, false>), grid, dim3(UT), 0, st, dD, a, c, items, n_items);
   else if (bf16)
-    hipLaunchKernelGGL((k_update<true, true>), grid, dim3(256), 0, st, dD, a, c, items, n_items);
+    hipLaunchKernelGGL((k_update<true, true>), grid, dim3(UT), 0, st, dD, a, c, items, n_items);
   else if (n_seeds > 1)
-    hipLaunchKernelGGL((k_update<false, false>), grid, dim3(256), 0, st, dD, a, c, items, n_items);
+    hipLaunchKernelGGL((k_update<false, false>), grid, dim3(UT), 0, st, dD, a, c, items, n_items);
   else
-    hipLaunchKernelGGL((k_update<false, true>), grid, dim3(256), 0, st, dD, a, c, items, n_items);
+    hipLaunchKernelGGL((k_update<false, true>), grid, dim3(UT), 0, st, dD, a, c, items, n_items);
   return hipGetLastError();
 }
 hipError_t launch_infer(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const FwdNet &N,

@@ -19,7 +19,7 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
 out = {}
 for c in tot:
     for k, v in tot[c].items():
-        if "iqlhip::k_" in k and ("forward" in k or "backward" in k or "update" in k):
+        if "iqlhip::k_" in k and any(w in k for w in ("forward", "backward", "update", "stage")):
             name = k.split("iqlhip::")[1].split("<")[0]
             out.setdefault(name, {})[c] = {"sum": v, "dispatches": cnt[c][k], "per_dispatch": v / cnt[c][k]}
 print(json.dumps(out, indent=1))

@@ -1,24 +1,26 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence under profiles/ (run on the GPU box through gpurun):
-#   tools/profile.sh <tag>        e.g. r01_c
+#   tools/profile.sh <tag>        e.g. r02
 # Passes: kernel trace + stats; PMC FETCH_SIZE; PMC WRITE_SIZE; PMC MFMA busy (each its own run:
 # the TCC counters do not fit one pass, and --pmc is never combined with other trace domains).
+# The profiled program is `python bench.py ...` itself (nothing between rocprofv3 and python).
 set -e
-TAG=${1:-r01_c}
+TAG=${1:-r02}
 OUT=$PWD/gpurun_out/prof_$TAG
-ARGS="--no-cpu-baseline --agents-per-gpu 0 --ensemble-q 0"
+ARGS="--no-cpu-baseline --no-relabel --agents-per-gpu 0 --ensemble-q 0 --min-timed-s 0.05"
 mkdir -p $OUT
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 3000 --warmup 300 $ARGS > $OUT/trace.json
 echo "trace done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python bench.py --steps 1000 --warmup 100 $ARGS > $OUT/fetch.json
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python bench.py --steps 500 --warmup 100 $ARGS > $OUT/fetch.json
 echo "fetch done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python bench.py --steps 1000 --warmup 100 $ARGS > $OUT/write.json
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python bench.py --steps 500 --warmup 100 $ARGS > $OUT/write.json
 echo "write done"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -- python bench.py --steps 1000 --warmup 100 $ARGS > $OUT/mfma.json || echo "mfma pass failed (counter set not available)"
-python tools/pmc_summary.py $OUT/fetch 1000 $OUT/pmc_fetch_size.json > /dev/null
-python tools/pmc_summary.py $OUT/write 1000 $OUT/pmc_write_size.json > /dev/null
-python tools/pmc_summary.py $OUT/mfma 1000 $OUT/pmc_mfma.json > /dev/null || true
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -- python bench.py --steps 500 --warmup 100 $ARGS > $OUT/mfma.json || echo "mfma pass failed (counter set not available)"
+python tools/pmc_summary.py $OUT/fetch 1 $OUT/pmc_fetch_size.json > /dev/null
+python tools/pmc_summary.py $OUT/write 1 $OUT/pmc_write_size.json > /dev/null
+python tools/pmc_summary.py $OUT/mfma 1 $OUT/pmc_mfma.json > /dev/null || true
+python tools/traffic_json.py $OUT/pmc_fetch_size.json $OUT/pmc_write_size.json $OUT/traffic.json
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 # keep only the summaries (the raw per-dispatch CSVs are tens of MB)
 rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/mfma
