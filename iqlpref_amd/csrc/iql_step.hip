@@ -1090,7 +1090,6 @@ constexpr int UNIT = UMAXI / 16; // in-feature tiles of a layer-1 strip, at most
 constexpr int USR = IQL_USR;     // rows of a layer-1 strip (16 or 32)
 constexpr int UOT = USR / 16;    // out-feature tiles of a strip
 constexpr int UWPO = UWAVES / UOT;  // waves sharing one out-feature tile (they split the in-feature tiles)
-constexpr int UNF4 = (USR * UMAXI / 4 + UT - 1) / UT;  // float4 of the strip's flat range per thread
 static_assert(UNP >= 1 && UNB >= 1 && UTO % URPP == 0, "update tile geometry");
 constexpr int UPD_TILE = UTO * (UTI + 4) > USR * (UMAXI + 4) ? UTO * (UTI + 4) : USR * (UMAXI + 4);
 constexpr int UPD_LDS = UPD_TILE + USR * (UMAXI + 4);  // floats of LDS per update work-group (~18 KB)
@@ -1203,19 +1202,22 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     // addresses, every line fully used.  (32 rather than 64 rows: the strips are the longest
     // work-groups of the launch, twice as many halves the tail.)
     const int TLD = Ipad + 4;
-    const int n4 = USR * Idim / 4;  // Odim = H is a multiple of 32: the strip is always 32 full rows
     const int64_t fbase = it.off_w + (int64_t)o0 * Idim, tbase = it.toff_w + (int64_t)o0 * Idim;
-    float4 pf[UNF4], mf[UNF4], vf[UNF4], tf[UNF4];
+    // one ELEMENT of the flat range per thread and pass (UNE passes cover 16 x 128 elements):
+    // the strip's Adam work is spread over all 512 threads instead of a quarter of them
+    constexpr int UNE = (USR * UMAXI + UT - 1) / UT;
+    const int n_el = USR * Idim;
+    float pf[UNE], mf[UNE], vf[UNE], tf[UNE];
     float pb, mb, vb, tb;  // branch-free (see the tiles below)
     auto load_state = [&]() {
 #pragma unroll
-      for (int k = 0; k < UNF4; ++k) {
-        const int e4 = tid + UT * k;
-        const int ec = e4 < n4 ? e4 : n4 - 1;  // branch-free: lanes past the end re-read the last element
-        pf[k] = __builtin_bit_cast(float4, ldg16(g_params + fbase + 4 * ec));
-        mf[k] = __builtin_bit_cast(float4, ldg16(g_m + fbase + 4 * ec));
-        vf[k] = __builtin_bit_cast(float4, ldg16(g_v + fbase + 4 * ec));
-        tf[k] = __builtin_bit_cast(float4, ldg16((has_target ? g_target + tbase : g_params + fbase) + 4 * ec));
+      for (int k = 0; k < UNE; ++k) {
+        const int e = tid + UT * k;
+        const int ec = e < n_el ? e : n_el - 1;  // branch-free: lanes past the end re-read the last element
+        pf[k] = ldg(g_params + fbase + ec);
+        mf[k] = ldg(g_m + fbase + ec);
+        vf[k] = ldg(g_v + fbase + ec);
+        tf[k] = ldg((has_target ? g_target + tbase : g_params + fbase) + ec);
       }
       const int ob_ = o0 + (tid & (USR - 1));  // < Odim = H always
       const int64_t eb = it.off_b + ob_;
@@ -1294,9 +1296,13 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
         }
       }
     };
-    chunk(0);  // straight-line first chunk: no loop pre-header to drain the state loads in
+    // (waves whose in-feature tile does not exist -- S + A <= 48: five of the eight -- load
+    // nothing: every fragment costs the CU's L1 port 16 cycles)
+    if (th < nit) {
+      chunk(0);  // straight-line first chunk: no loop pre-header to drain the state loads in
 #pragma unroll 1
-    for (int k0 = UKC; k0 < nk; k0 += UKC) chunk(k0);
+      for (int k0 = UKC; k0 < nk; k0 += UKC) chunk(k0);
+    }
     if constexpr (!LAT) load_state();
     // C/D layout: lane (r, q) of acc[tb] holds dW[o0 + 16 wo + r][16 (th + 2 tb) + 4 q + k]
 #pragma unroll
@@ -1313,40 +1319,26 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     T *wc = reinterpret_cast<T *>(it.wc);
     T *tc = reinterpret_cast<T *>(it.tc);
     const int nkw = Kw / P::KM;
-    // Adam + Polyak on the flat range, four consecutive elements per access; the new weights
-    // (and targets) go back to LDS in [row][in-feature] order for the compute copies
-    auto flat_update = [&](int e4, float4 p4, float4 m4, float4 v4, float4 t4) {
-      float p[4] = {p4.x, p4.y, p4.z, p4.w}, m[4] = {m4.x, m4.y, m4.z, m4.w};
-      float v[4] = {v4.x, v4.y, v4.z, v4.w}, tv[4] = {t4.x, t4.y, t4.z, t4.w}, g[4];
-      int ol = (4 * e4) / Idim, i = 4 * e4 - ol * Idim;
+    // Adam + Polyak on the flat range; the new weights (and targets) go back to LDS in
+    // [row][in-feature] order for the compute copies
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        g[k] = P::round(tile[ol * TLD + i]);
-        adam_apply(p[k], m[k], v[k], g[k], coef, neg_step);
-        tile[ol * TLD + i] = p[k];
+    for (int k = 0; k < UNE; ++k) {
+      const int e = tid + UT * k;
+      if (e < n_el) {
+        const int ol = e / Idim, i = e - ol * Idim;
+        const float g = P::round(tile[ol * TLD + i]);
+        float p_ = pf[k], m_ = mf[k], v_ = vf[k];
+        adam_apply(p_, m_, v_, g, coef, neg_step);
+        tile[ol * TLD + i] = p_;
+        stg(g_params + fbase + e, p_), stg(g_m + fbase + e, m_), stg(g_v + fbase + e, v_);
+        if (g_grads) stg(g_grads + fbase + e, g);
         if (has_target) {
-          tv[k] = polyak(D, tv[k], p[k]);
-          tile2[ol * TLD + i] = tv[k];
+          const float t_ = polyak(D, tf[k], p_);
+          tile2[ol * TLD + i] = t_;
+          stg(g_target + tbase + e, t_);
         }
-        if (++i == Idim) i = 0, ++ol;
       }
-      stg16(g_params + fbase + 4 * e4, make_float4(p[0], p[1], p[2], p[3]));
-      stg16(g_m + fbase + 4 * e4, make_float4(m[0], m[1], m[2], m[3]));
-      stg16(g_v + fbase + 4 * e4, make_float4(v[0], v[1], v[2], v[3]));
-      if (g_grads) stg16(g_grads + fbase + 4 * e4, make_float4(g[0], g[1], g[2], g[3]));
-      if (has_target) stg16(g_target + tbase + 4 * e4, make_float4(tv[0], tv[1], tv[2], tv[3]));
-    };
-#pragma unroll
-    for (int k = 0; k < UNF4; ++k) {
-      const int e4 = tid + UT * k;
-      if (e4 < n4) flat_update(e4, pf[k], mf[k], vf[k], tf[k]);
     }
-    for (int e4 = tid + UT * UNF4; e4 < n4; e4 += UT)  // (never taken: UNF4 covers S + A <= 128)
-      flat_update(e4, __builtin_bit_cast(float4, ldg16(g_params + fbase + 4 * e4)),
-                  __builtin_bit_cast(float4, ldg16(g_m + fbase + 4 * e4)),
-                  __builtin_bit_cast(float4, ldg16(g_v + fbase + 4 * e4)),
-                  has_target ? __builtin_bit_cast(float4, ldg16(g_target + tbase + 4 * e4))
-                             : make_float4(0.f, 0.f, 0.f, 0.f));
     if (tid < USR) {
       const int64_t e = it.off_b + o0 + tid;
       const float g = P::round(bgrad[tid]);
@@ -1430,8 +1422,34 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       }
     }
   };
+  // Operand panels through LDS (bf16, batch <= 256: all k-steps fit one panel): the tile's X
+  // panel (2 in-feature tiles) and Z panel (4 out-feature tiles) are 48 distinct 1 KiB fragments,
+  // but the 8 waves would load 128 of them between them (each wave its own X and Z fragments),
+  // all through the CU's one L1 port at 16 cycles per KiB.  Instead every wave DMAs 6 fragments
+  // straight into LDS (global_load_lds_dwordx4: lane l lands at base + 16 l, no VGPRs) and the
+  // waves read theirs back with conflict-free 16-byte LDS loads.
+  constexpr int NPIECE = 16 + 8 * (UTO / 16);  // X: 2 tiles x 8 k-steps, Z: UTO / 16 tiles x 8
+  __shared__ __attribute__((aligned(16))) uint4 pan[BF16 ? NPIECE * 64 : 1];
+  const bool use_dma = BF16 && nk <= UKC;
   uint4 xf0[UKC], zf0[UKC][UNB];
-  load_frags(0, xf0, zf0);
+  if (use_dma) {
+    constexpr int PPW = NPIECE / UWAVES;
+    static_assert(NPIECE % UWAVES == 0, "fragments per wave");
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int pc = wave * PPW + j;  // (scalar) fragment id: [0, 16) X, [16, NPIECE) Z
+      const bool isx = pc < 16;
+      const int t = isx ? (pc >> 3) : ((pc - 16) >> 3), ks = pc & 7;
+      if (ks < nk) {
+        const int ztile = (o0 >> 4) + t < ntile_o ? (o0 >> 4) + t : ntile_o - 1;
+        const T *src = isx ? Xsrc + frag_off<P>((i0 >> 4) + t, ks, nk, lane) : Zsrc + frag_off<P>(ztile, ks, nk, lane);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(pan + pc * 64), 16, 0, 0);
+      }
+    }
+  } else {
+    load_frags(0, xf0, zf0);
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- 1. optimiser state, row order: thread -> (row tr + 16 pass, columns 4 tc .. +3) ----
@@ -1473,6 +1491,19 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   STAMP(2, 1);
 
   __builtin_amdgcn_sched_barrier(0);
+  if (use_dma) {
+    // the DMAs (and, in LAT mode, the state loads issued behind them) have landed; the barrier
+    // makes the other waves' fragments visible
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < UKC; ++ks) {
+      const int kk = ks < nk ? ks : nk - 1;
+      xf0[ks] = pan[(wi * 8 + kk) * 64 + lane];
+#pragma unroll
+      for (int b = 0; b < UNB; ++b) zf0[ks][b] = pan[(16 + (UNB * wo + b) * 8 + kk) * 64 + lane];
+    }
+  }
   mma_frags(0, xf0, zf0);
 #pragma unroll 1
   for (int k0 = UKC; k0 < nk; k0 += UKC) {
