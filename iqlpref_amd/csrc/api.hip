@@ -20,8 +20,8 @@ hipError_t launch_forward(bool, const TrainerDesc &, const TrainerDesc *, const 
                           int n_seeds, hipStream_t);
 hipError_t launch_backward(bool, const TrainerDesc &, const TrainerDesc *, const DevArgs *, DevCtr *,
                            int n_seeds, hipStream_t);
-hipError_t launch_stage(const TrainerDesc &, const TrainerDesc *, const DevArgs *, const DevCtr *, int n_seeds,
-                        hipStream_t);
+hipError_t launch_stage(bool, const TrainerDesc &, const TrainerDesc *, const DevArgs *, const DevCtr *,
+                        int n_seeds, hipStream_t);
 int strip_rows();
 int update_lds_floats();
 hipError_t launch_update(bool, const TrainerDesc *, const DevArgs *, DevCtr *, const UpdItem *, int,
@@ -392,7 +392,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
     add((size_t)H * H * es);  // w2ct
     add((size_t)H * outpad[n] * es);  // w3t
   }
-  add((size_t)D.xrows * D.BP * es);
+  add((size_t)2 * D.xrows * D.BP * es);
   add((size_t)B * 2 * 4);
   add((size_t)B * A * 4);
   add((size_t)NT * 2 * H * D.BP * es);
@@ -481,7 +481,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
     N.w2ct = carve<char>(p, (size_t)H * H * es);
     N.w3t = carve<char>(p, (size_t)H * outpad[n] * es);
   }
-  D.xT = carve<char>(p, (size_t)D.xrows * D.BP * es);
+  D.xT = carve<char>(p, (size_t)2 * D.xrows * D.BP * es);
   D.rd = carve<float>(p, (size_t)B * 2);
   D.actf = carve<float>(p, (size_t)B * A);
   D.hT = carve<char>(p, (size_t)NT * 2 * H * D.BP * es);
@@ -640,7 +640,7 @@ extern "C" int iqlhip_trainer_get_timing(iqlhip_trainer *t, double avg_ms[3], in
 }
 
 static int enqueue_step(iqlhip_trainer *t, hipStream_t st) {
-  if (!t->D.prefetch) HIP_TRY(launch_stage(t->D, t->ddesc, t->dargs, t->dctr, 1, st));
+  if (!t->D.prefetch) HIP_TRY(launch_stage(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, 1, st));
   HIP_TRY(launch_forward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, 1, st));
   HIP_TRY(launch_backward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, 1, st));
   HIP_TRY(launch_update(t->bf16, t->ddesc, t->dargs, t->dctr, t->ditems, t->n_items, 1, st));
@@ -670,12 +670,12 @@ static int run_steps(iqlhip_trainer *t, const DevArgs &args_in, int64_t n_steps,
                      hipStream_t st) {
   HIP_TRY(push_args(t, args_in, n_steps, st));
   // the first step's batch (later steps are staged by the update kernel of the step before)
-  if (t->D.prefetch) HIP_TRY(launch_stage(t->D, t->ddesc, t->dargs, t->dctr, 1, st));
+  if (t->D.prefetch) HIP_TRY(launch_stage(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, 1, st));
   int64_t done = 0;
   if (t->timing) {
     // one event pair per kernel: serialises the stream a little; diagnostic mode only
     for (; done < n_steps; ++done) {
-      if (!t->D.prefetch) HIP_TRY(launch_stage(t->D, t->ddesc, t->dargs, t->dctr, 1, st));
+      if (!t->D.prefetch) HIP_TRY(launch_stage(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, 1, st));
       HIP_TRY(hipEventRecord(t->ev[0], st));
       HIP_TRY(launch_forward(t->bf16, t->D, t->ddesc, t->dargs, t->dctr, 1, st));
       HIP_TRY(hipEventRecord(t->ev[1], st));
@@ -889,7 +889,7 @@ extern "C" int iqlhip_group_destroy(iqlhip_group *g) {
 
 static int group_enqueue_step(iqlhip_group *g, hipStream_t st) {
   iqlhip_trainer *t0 = g->tr[0];
-  if (!t0->D.prefetch) HIP_TRY(launch_stage(t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
+  if (!t0->D.prefetch) HIP_TRY(launch_stage(t0->bf16, t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
   HIP_TRY(launch_forward(t0->bf16, t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
   HIP_TRY(launch_backward(t0->bf16, t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
   HIP_TRY(launch_update(t0->bf16, g->gdesc, g->gargs, g->gctr, g->gitems, t0->n_items, g->K, st));
@@ -939,13 +939,13 @@ extern "C" int iqlhip_group_train_steps(iqlhip_group *g, const iqlhip_replay_vie
   HIP_TRY(hipMemcpyAsync(g->gargs, g->harg[slot], sizeof(DevArgs) * g->K, hipMemcpyHostToDevice, st));
   HIP_TRY(hipEventRecord(g->harg_ev[slot], st));
   g->harg_used[slot] = true;
-  if (g->tr[0]->D.prefetch) HIP_TRY(launch_stage(g->tr[0]->D, g->gdesc, g->gargs, g->gctr, g->K, st));
+  if (g->tr[0]->D.prefetch) HIP_TRY(launch_stage(g->tr[0]->bf16, g->tr[0]->D, g->gdesc, g->gargs, g->gctr, g->K, st));
   // ---- the steps: hipGraphs of `graph_unroll` steps, the remainder eagerly ----
   int64_t done = 0;
   if (g->timing) {  // one event pair per kernel; diagnostic mode only
     iqlhip_trainer *t0 = g->tr[0];
     for (; done < n_steps; ++done) {
-      if (!t0->D.prefetch) HIP_TRY(launch_stage(t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
+      if (!t0->D.prefetch) HIP_TRY(launch_stage(t0->bf16, t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
       HIP_TRY(hipEventRecord(g->ev[0], st));
       HIP_TRY(launch_forward(t0->bf16, t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
       HIP_TRY(hipEventRecord(g->ev[1], st));

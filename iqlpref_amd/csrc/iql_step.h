@@ -62,7 +62,7 @@ struct TrainerDesc {
   uint64_t seed;
   // workspace (T = compute type)
   float *stage_rows;  // [B][stage_stride] the batch of the step about to run (k_stage / k_update)
-  void *xT;       // [xrows][B]   layer-1 input (s|a), feature-major
+  void *xT;       // [2][xrows][B] layer-1 input (s|a), feature-major; plane = step parity
   float *rd;      // [B][2]       reward, done
   float *actf;    // [B][A]       actions (fp32, actor loss)
   void *hT;       // [ntrain][2][H][B] hidden activations (post ReLU / dropout)

@@ -340,11 +340,20 @@ __device__ __forceinline__ void mlp_slab(const FwdNet &N, const TrainerDesc &D, 
 // by k_stage for the first step of a call (or every step when prefetching is off).
 // 16 lanes per row, 16-byte accesses (row strides are multiples of 4 floats).
 // ------------------------------------------------------------------------
+// The same pass leaves what k_update needs of the batch besides the rows: the layer-1 input
+// (s | a) in compute precision, feature-major fragment layout (xT, the X operand of the layer-1
+// weight-gradient GEMM), reward / done (rd) and the actions in fp32 (actf).
 // (tid >> 4 rows per pass: 16 for a 256-thread work-group, 32 for k_update's 512)
+template <bool BF16>
 __device__ __forceinline__ void stage_rows16(const TrainerDesc &D, const DevArgs &A, int64_t step, int row0,
                                              int row_step, int tid) {
+  using P = Prec<BF16>;
+  using T = typename P::T;
   const int rr = tid >> 4, l16 = tid & 15;
-  const int B = D.B, nq = D.stage_stride >> 2;
+  const int B = D.B, nq = D.stage_stride >> 2, S = D.S, SA = D.S + D.A, nkb = D.BP / P::KM;
+  // (two planes, by step parity: the update kernel of step t reads plane t & 1 while its idle
+  // work-groups already fill plane (t + 1) & 1)
+  T *const xT = reinterpret_cast<T *>(D.xT) + (size_t)(step & 1) * D.xrows * D.BP;
   for (int row = row0 + rr; row < B; row += row_step) {
     int64_t ix;
     if (A.idx_mode == 1)
@@ -356,15 +365,27 @@ __device__ __forceinline__ void stage_rows16(const TrainerDesc &D, const DevArgs
     ix = ix < 0 ? 0 : (ix >= A.n_rows ? A.n_rows - 1 : ix);
     const float *src = A.rows + (size_t)ix * A.row_stride;
     float *dst = D.stage_rows + (size_t)row * D.stage_stride;
-    for (int c = l16; c < nq; c += 16) stg16(dst + 4 * c, __builtin_bit_cast(float4, ldg16(src + 4 * c)));
+    for (int c = l16; c < nq; c += 16) {
+      const float4 v4 = __builtin_bit_cast(float4, ldg16(src + 4 * c));
+      stg16(dst + 4 * c, v4);
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = 4 * c + e;  // [0, S + A): s | a, then r, d
+        if (col < SA) stg(xT + fidx<P>(col, row, nkb), P::from_f32(v[e]));
+        if (col >= S && col < SA) stg(D.actf + (size_t)row * D.A + (col - S), v[e]);
+        if (col >= SA && col < SA + 2) stg(D.rd + (size_t)row * 2 + (col - SA), v[e]);
+      }
+    }
   }
 }
 
+template <bool BF16>
 __global__ __launch_bounds__(256) void k_stage(const TrainerDesc *__restrict__ Dp,
                                                const DevArgs *__restrict__ Ap,
                                                const DevCtr *__restrict__ Cp) {
   Dp += blockIdx.y, Ap += blockIdx.y, Cp += blockIdx.y;
-  stage_rows16(*Dp, *Ap, Cp->ctr[0], blockIdx.x * 16, gridDim.x * 16, threadIdx.x);
+  stage_rows16<BF16>(*Dp, *Ap, Cp->ctr[0], blockIdx.x * 16, gridDim.x * 16, threadIdx.x);
 }
 
 __device__ __forceinline__ void write_adam_coef(const TrainerDesc &D, const DevArgs &A, int64_t t1,
@@ -436,10 +457,8 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   const int B = D.B, BP = D.BP, OUTW = D.OUTW, k1max = D.k1max;
   const float *const stage = D.stage_rows;
   const unsigned sstride = (unsigned)D.stage_stride;
-  const int n_act = D.A, s_dim = D.S, next_off = D.next_off;
   float *const g_outs = D.outs;
-  void *const g_hT = D.hT, *const g_xT = D.xT;
-  float *const g_rd = D.rd, *const g_actf = D.actf;
+  void *const g_hT = D.hT;
   const int64_t step = Cp->ctr[0];  // dropout masks only
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -455,9 +474,8 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   // lane l16 takes columns 4 l16 .. +3 and 64 + 4 l16 .. +3 of its row's input segment as two
   // 16-byte loads (segments start on 16-byte boundaries: in_off is 0 or next_off).  Clamped,
   // never branching: columns beyond the segment re-read its last 16 bytes and are zeroed at use.
-  // The staging evaluation (q1, input s|a) also picks r and d up: they follow a in the row.
   const int rr = tid >> 4, l16 = tid & 15;
-  const int lim4 = (N.stage ? next_off : round_up(N.in_dim, 4)) - 4;  // last valid 16-byte column group
+  const int lim4 = round_up(N.in_dim, 4) - 4;  // last valid 16-byte column group
   float4 xq[MT][2];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -510,11 +528,9 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   }
   STAMP(0, 1);
 
-  // ---- layer-1 input into LDS (+ the batch staging for k_update: evaluation 0, part 0) ----
+  // ---- layer-1 input into LDS ----
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    const int row = slab * ROWS + 16 * m + rr;
-    const bool st = N.stage && part == 0 && row < B;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = 4 * l16 + 64 * j;
@@ -529,22 +545,6 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
           *reinterpret_cast<uint2 *>(xs + (16 * m + rr) * K1P + c) = u;
         } else {
           *reinterpret_cast<float4 *>(xs + (16 * m + rr) * K1P + c) = make_float4(tv[0], tv[1], tv[2], tv[3]);
-        }
-        if (st) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (c + e < N.in_dim) stg(reinterpret_cast<T *>(g_xT) + fidx<P>(c + e, row, BP / P::KM), tv[e]);
-        }
-      }
-      if (st) {  // columns [S, S + A) are the action, S + A the reward, S + A + 1 the done flag
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int col = c + e;
-          if (col <= lim4 + 3) {  // (clamped lanes hold re-read data)
-            if (col >= s_dim && col < s_dim + n_act) stg(g_actf + (size_t)row * n_act + (col - s_dim), v[e]);
-            if (col >= s_dim + n_act && col < s_dim + n_act + 2)
-              stg(g_rd + (size_t)row * 2 + (col - s_dim - n_act), v[e]);
-          }
         }
       }
     }
@@ -820,10 +820,13 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
 
   // ---- the loss inputs first: loads return in order, these must not queue behind the
   // weight stream requested next.  Thread (row tid / 16, lane16 = tid % 16). ----
-  const int lrow = tid >> 4, lj = tid & 15;
+  // (512 threads: waves 0-3 own the loss lanes and the dZ1 GEMM, all eight share the dZ2 phase --
+  // a VALU chain per hidden unit that one wave per SIMD issued at half rate)
+  const bool lo4 = wave < 4;  // scalar
+  const int lrow = (tid & 255) >> 4, lj = tid & 15;
   const int brow = slab * SLAB + lrow;
   float pv[FIN_NC][SPL];
-  {
+  if (lo4) {
     const float *o = g_outs + (size_t)brow * OUTW;
 #pragma unroll
     for (int c = 0; c < FIN_NC; ++c) {
@@ -833,13 +836,15 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
       for (int p = 0; p < SPL; ++p) pv[c][p] = ldg(o + ((unsigned)p * (unsigned)(B * OUTW) + cc));
     }
   }
-  const float rew = ldg(g_rd + (size_t)brow * 2), done = ldg(g_rd + (size_t)brow * 2 + 1);
-  float actv[2], lsv[2];
+  float rew = 0.f, done = 0.f, actv[2] = {0.f, 0.f}, lsv[2] = {0.f, 0.f};
+  if (lo4) {
+    rew = ldg(g_rd + (size_t)brow * 2), done = ldg(g_rd + (size_t)brow * 2 + 1);
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {  // outputs lj and lj + 16 (A <= 32); clamped, unused beyond A
-    const int jc = lj + 16 * h < n_act ? lj + 16 * h : n_act - 1;
-    actv[h] = ldg(g_actf + (size_t)brow * n_act + jc);
-    lsv[h] = ldg(g_ls + jc);
+    for (int h = 0; h < 2; ++h) {  // outputs lj and lj + 16 (A <= 32); clamped, unused beyond A
+      const int jc = lj + 16 * h < n_act ? lj + 16 * h : n_act - 1;
+      actv[h] = ldg(g_actf + (size_t)brow * n_act + jc);
+      lsv[h] = ldg(g_ls + jc);
+    }
   }
   // keep these loads AHEAD of the weight stream (the scheduler otherwise moves some of them
   // behind it, and loads return in order)
@@ -847,7 +852,11 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   // ---- request everything else that does not depend on the loss, in the order it is
   // consumed: W3 and h2 for the dZ2 phase, then this part of W2^T for the GEMM, h1 for its
   // epilogue.  All unconditional (clamped). ----
-  const int c2 = tid < H ? tid : H - 1;  // hidden unit this thread owns in the dZ2 phase
+  // dZ2 phase: thread -> hidden unit c2 and (H = 256: 512 threads) one of two groups of 8 rows
+  constexpr int RG = H == 256 ? 2 : 1, RPT = SLAB / RG;  // row groups; rows per thread
+  const int c2 = (tid & 255) < H ? (tid & 255) : H - 1;
+  const int rg = RG == 2 ? (tid >> 8) : 0;
+  const bool dz2_on = (tid & 255) < H && (RG == 2 || tid < 256);
   // W3^T [H][out_pad]: this unit's weights to every output, 8 (bf16) / 4 (fp32) per 16-byte load
   constexpr int W3G = 32 / P::EPV;  // 16-byte groups covering 32 outputs
   uint4 w3q[W3G];
@@ -857,29 +866,29 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     for (int g = 0; g < W3G; ++g)
       if (g * P::EPV < out_pad) w3q[g] = ldg16(w3row + g * P::EPV);  // (scalar guard: no redundant loads)
   }
-  float h2v[16];
+  float h2v[RPT];
   {
     const T *h2T = g_hT + (size_t)(net * 2 + 1) * H * BP;
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4)
-      load4T<BF16>(h2T + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), &h2v[4 * g4]);
+    for (int g4 = 0; g4 < RPT / 4; ++g4)
+      load4T<BF16>(h2T + fidx<P>(c2, slab * SLAB + RPT * rg + 4 * g4, nkb), &h2v[4 * g4]);
   }
   __builtin_amdgcn_sched_barrier(0);
   uint4 w2t[K::NK2];
-  {
+  float h1v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (lo4) {
     const T *W2Tw = reinterpret_cast<const T *>(p_w2ct) + (size_t)tile0 * K::NK2 * 64 * P::EPV;
 #pragma unroll
     for (int ks = 0; ks < K::NK2; ++ks) w2t[ks] = ldg16(W2Tw + ks * 64 * P::EPV + lane * P::EPV);
+    load4T<BF16>(g_hT + (size_t)(net * 2 + 0) * H * BP + fidx<P>(16 * tile0 + r, slab * SLAB + 4 * q, nkb), h1v);
   }
-  float h1v[4];
-  load4T<BF16>(g_hT + (size_t)(net * 2 + 0) * H * BP + fidx<P>(16 * tile0 + r, slab * SLAB + 4 * q, nkb), h1v);
   STAMP(1, 1);
 
   // ---- finish the forward outputs of this slab (sum of the parts, rounding, tanh) ----
 #pragma unroll
   for (int c = 0; c < FIN_NC; ++c) {
     const int col = lj + 16 * c;
-    if (col < OUTW) {
+    if (lo4 && col < OUTW) {
       float sum = pv[c][0];
 #pragma unroll
       for (int p = 1; p < SPL; ++p) sum += pv[c][p];
@@ -891,7 +900,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   __syncthreads();
 
   // ---- per-row loss terms and d(loss)/d(out)  (ref:581-637), LDS layout [j][16 rows] ----
-  {
+  if (lo4) {
     const float *f = fin + lrow * FIN_LD;
     LossIn lin;
     // TwinQ.forward = min(q1, q2) of the target critics (ref:531-533, 583-584); min over all E
@@ -928,18 +937,18 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     stg(g_lsp + (size_t)slab * n_act + j, s);
   }
   // d(out), feature-major, for the layer-3 weight gradient
-  for (int e = tid; part == 0 && e < out_dim * SLAB; e += 256) {
+  for (int e = tid; part == 0 && e < out_dim * SLAB; e += 512) {
     const int j = e / SLAB, rr = e - j * SLAB;
     stg(g_dz3T + (size_t)net * opmax * BP + fidx<P>(j, slab * SLAB + rr, nkb),
         P::from_f32(dz3[j * SLAB + rr]));
   }
 
   // ---- dZ2 = (dZ3 W3) * relu'(h2)   (VALU: K = out_dim <= 32) ----
-  if (tid < H) {
+  if (dz2_on) {
     T *dst = g_dz2T + (size_t)net * H * BP;
-    float s[SLAB];
+    float s[RPT];
 #pragma unroll
-    for (int rr = 0; rr < SLAB; ++rr) s[rr] = 0.f;
+    for (int rr = 0; rr < RPT; ++rr) s[rr] = 0.f;
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
       if (j < out_dim) {
@@ -955,8 +964,8 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
           w3j = fs[j % 4];
         }
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const float4 dv = *reinterpret_cast<const float4 *>(&dz3[j * SLAB + 4 * g4]);
+        for (int g4 = 0; g4 < RPT / 4; ++g4) {
+          const float4 dv = *reinterpret_cast<const float4 *>(&dz3[j * SLAB + RPT * rg + 4 * g4]);
           s[4 * g4] += dv.x * w3j, s[4 * g4 + 1] += dv.y * w3j;
           s[4 * g4 + 2] += dv.z * w3j, s[4 * g4 + 3] += dv.w * w3j;
         }
@@ -964,7 +973,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     }
     const bool mine = c2 / C::HQ == part;  // the part that owns this hidden unit stores its dZ2
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
+    for (int g4 = 0; g4 < RPT / 4; ++g4) {
       float outv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -972,9 +981,9 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
         float sv = P::round(s[rr]);
         if (drop_on) sv = P::round(sv * drop_scale);
         outv[i] = h2v[rr] > 0.f ? sv : 0.f;
-        dz2s[rr * HP + c2] = P::from_f32(outv[i]);
+        dz2s[(RPT * rg + rr) * HP + c2] = P::from_f32(outv[i]);
       }
-      if (mine) store4T<BF16>(dst + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), outv);
+      if (mine) store4T<BF16>(dst + fidx<P>(c2, slab * SLAB + RPT * rg + 4 * g4, nkb), outv);
     }
   }
   __syncthreads();
@@ -987,7 +996,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   }
 
   // ---- dZ1 = (dZ2 W2) * relu'(h1)   (MFMA, B operand = transposed copy; one n-tile per wave) ----
-  {
+  if (lo4) {
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     const T *xrow = dz2s + r * HP + P::EPV * q;
 #pragma unroll
@@ -1072,16 +1081,13 @@ constexpr int UKC = 8;  // batch k-steps per register chunk in the weight-gradie
 //   4. the new weights go through LDS once more for the transposed compute copy.
 // Rows of the first layer are not 16-byte aligned (in_dim 29, 37, ...): that layer
 // uses a scalar path over the same tile.
-constexpr int UT = 512;          // threads of an update work-group: 8 waves, two per SIMD (the Adam
-                                 // phase is bound by VALU issue: one wave per SIMD used half of it)
-constexpr int UWAVES = UT / 64;
+// Threads of an update work-group (template parameter of k_update): 512 = 8 waves, two per SIMD,
+// for one seed per launch (the Adam pass is bound by VALU issue: one wave per SIMD used half of
+// it); 256 for several seeds per launch (four 126-VGPR work-groups per CU measured faster there).
 constexpr int UTO = 64;          // tile: out-features
 constexpr int UTI = 32;          // tile: in-features
 constexpr int ULD = UTI + 4;     // LDS row stride (floats)
 constexpr int UTPR = UTI / 4;    // threads per tile row (float4 each)
-constexpr int URPP = UT / UTPR;  // rows per pass
-constexpr int UNP = UTO / URPP;  // passes
-constexpr int UNB = (UTO / 16) / (UWAVES / 2);  // out-feature tiles per wave in the tile GEMM
 constexpr int UMAXI = 128;       // S + A <= 128 (host check)
 constexpr int UNIT = UMAXI / 16; // in-feature tiles of a layer-1 strip, at most
 #ifndef IQL_USR
@@ -1089,18 +1095,22 @@ constexpr int UNIT = UMAXI / 16; // in-feature tiles of a layer-1 strip, at most
 #endif
 constexpr int USR = IQL_USR;     // rows of a layer-1 strip (16 or 32)
 constexpr int UOT = USR / 16;    // out-feature tiles of a strip
-constexpr int UWPO = UWAVES / UOT;  // waves sharing one out-feature tile (they split the in-feature tiles)
-static_assert(UNP >= 1 && UNB >= 1 && UTO % URPP == 0, "update tile geometry");
 constexpr int UPD_TILE = UTO * (UTI + 4) > USR * (UMAXI + 4) ? UTO * (UTI + 4) : USR * (UMAXI + 4);
 constexpr int UPD_LDS = UPD_TILE + USR * (UMAXI + 4);  // floats of LDS per update work-group (~18 KB)
 
-template <bool BF16, bool LAT>
+template <bool BF16, bool LAT, int UT>
 __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
                                             const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
                                             const UpdItem *__restrict__ items, int n_items,
                                             const int blk) {
   using P = Prec<BF16>;
   using T = typename P::T;
+  constexpr int UWAVES = UT / 64;
+  constexpr int URPP = UT / UTPR;                  // tile rows per pass
+  constexpr int UNP = UTO / URPP;                  // passes
+  constexpr int UNB = (UTO / 16) / (UWAVES / 2);   // out-feature tiles per wave in the tile GEMM
+  constexpr int UWPO = UWAVES / UOT;               // waves sharing a strip's out-feature tile
+  static_assert(UNP >= 1 && UNB >= 1 && UTO % URPP == 0, "update tile geometry");
   const TrainerDesc &D = *Dp;
   const DevArgs &A = *Ap;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1178,7 +1188,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     // tiles work (random HBM rows + TLB misses leave the next k_forward's critical path); possible
     // iff that step's indices are known
     if (D.prefetch && (A.idx_mode == 0 || (A.idx_mode == 1 && t1 - A.base_step < A.n_steps)))
-      stage_rows16(D, A, t1, it.o0 * (UT / 16), it.i0 * (UT / 16), tid);
+      stage_rows16<BF16>(D, A, t1, it.o0 * (UT / 16), it.i0 * (UT / 16), tid);
     return;
   }
   const int L = it.layer;
@@ -1228,7 +1238,8 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     STAMP(2, 1);
     // dW1^T strip: wave w = out-feature tile (w & 1) against the in-feature tiles of parity
     // (w >> 1): every element is produced by one wave, k-steps in order (no cross-wave sums)
-    const T *Xsrc = reinterpret_cast<const T *>(it.Xsrc);
+    // layer-1 input of THIS step (t1 - 1): plane (t1 - 1) & 1 of xT
+    const T *Xsrc = reinterpret_cast<const T *>(it.Xsrc) + (size_t)((t1 - 1) & 1) * D.xrows * BP;
     const T *Zsrc = reinterpret_cast<const T *>(it.Zsrc);
     const int nit = Ipad >> 4;
     const int wo = wave % UOT, th = wave / UOT;
@@ -1296,7 +1307,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
         }
       }
     };
-    // (waves whose in-feature tile does not exist -- S + A <= 48: five of the eight -- load
+    // (waves whose in-feature tile does not exist -- S + A <= 48 at 512 threads: five of the eight -- load
     // nothing: every fragment costs the CU's L1 port 16 cycles)
     if (th < nit) {
       chunk(0);  // straight-line first chunk: no loop pre-header to drain the state loads in
@@ -1422,34 +1433,11 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       }
     }
   };
-  // Operand panels through LDS (bf16, batch <= 256: all k-steps fit one panel): the tile's X
-  // panel (2 in-feature tiles) and Z panel (4 out-feature tiles) are 48 distinct 1 KiB fragments,
-  // but the 8 waves would load 128 of them between them (each wave its own X and Z fragments),
-  // all through the CU's one L1 port at 16 cycles per KiB.  Instead every wave DMAs 6 fragments
-  // straight into LDS (global_load_lds_dwordx4: lane l lands at base + 16 l, no VGPRs) and the
-  // waves read theirs back with conflict-free 16-byte LDS loads.
-  constexpr int NPIECE = 16 + 8 * (UTO / 16);  // X: 2 tiles x 8 k-steps, Z: UTO / 16 tiles x 8
-  __shared__ __attribute__((aligned(16))) uint4 pan[BF16 ? NPIECE * 64 : 1];
-  const bool use_dma = BF16 && nk <= UKC;
+  // (Tried: the operand panels of a tile through LDS-DMA -- 48 distinct fragments instead of the
+  // 128 the eight waves load between them.  No gain: 3.24 vs 3.14 us per tile work-group, the
+  // wait for ALL fragments plus a barrier costs what the L1 port saves.)
   uint4 xf0[UKC], zf0[UKC][UNB];
-  if (use_dma) {
-    constexpr int PPW = NPIECE / UWAVES;
-    static_assert(NPIECE % UWAVES == 0, "fragments per wave");
-#pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-      const int pc = wave * PPW + j;  // (scalar) fragment id: [0, 16) X, [16, NPIECE) Z
-      const bool isx = pc < 16;
-      const int t = isx ? (pc >> 3) : ((pc - 16) >> 3), ks = pc & 7;
-      if (ks < nk) {
-        const int ztile = (o0 >> 4) + t < ntile_o ? (o0 >> 4) + t : ntile_o - 1;
-        const T *src = isx ? Xsrc + frag_off<P>((i0 >> 4) + t, ks, nk, lane) : Zsrc + frag_off<P>(ztile, ks, nk, lane);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(pan + pc * 64), 16, 0, 0);
-      }
-    }
-  } else {
-    load_frags(0, xf0, zf0);
-  }
+  load_frags(0, xf0, zf0);
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- 1. optimiser state, row order: thread -> (row tr + 16 pass, columns 4 tc .. +3) ----
@@ -1491,19 +1479,6 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   STAMP(2, 1);
 
   __builtin_amdgcn_sched_barrier(0);
-  if (use_dma) {
-    // the DMAs (and, in LAT mode, the state loads issued behind them) have landed; the barrier
-    // makes the other waves' fragments visible
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < UKC; ++ks) {
-      const int kk = ks < nk ? ks : nk - 1;
-      xf0[ks] = pan[(wi * 8 + kk) * 64 + lane];
-#pragma unroll
-      for (int b = 0; b < UNB; ++b) zf0[ks][b] = pan[(16 + (UNB * wo + b) * 8 + kk) * 64 + lane];
-    }
-  }
   mma_frags(0, xf0, zf0);
 #pragma unroll 1
   for (int k0 = UKC; k0 < nk; k0 += UKC) {
@@ -1602,7 +1577,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 // __global__ wrappers
 // ------------------------------------------------------------------------
 template <bool BF16, int H>
-__global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict__ Dp,
+__global__ __launch_bounds__(512) void k_backward(const TrainerDesc *__restrict__ Dp,
                                                   const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
                                                   const int nslab, const int ntrain) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1610,14 +1585,14 @@ __global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict_
 }
 
 template <bool BF16, bool LAT>
-__global__ __launch_bounds__(UT, LAT ? 2 : (BF16 ? 4 : 3)) void k_update(const TrainerDesc *__restrict__ Dp,
+__global__ __launch_bounds__(LAT ? 512 : 256, LAT ? 2 : (BF16 ? 4 : 3)) void k_update(const TrainerDesc *__restrict__ Dp,
                                                              const DevArgs *__restrict__ Ap,
                                                              DevCtr *__restrict__ Cp,
                                                              const UpdItem *__restrict__ items, int n_items) {
   // group launch: blockIdx.y = seed; grid.x is padded to a multiple of 8 (so that block -> XCD
   // stays blockIdx.x & 7 for every seed), the blocks behind the misc block have nothing to do
   if ((int)blockIdx.x > n_items) return;
-  update_body<BF16, LAT>(Dp + blockIdx.y, Ap + blockIdx.y, Cp + blockIdx.y,
+  update_body<BF16, LAT, (LAT ? 512 : 256)>(Dp + blockIdx.y, Ap + blockIdx.y, Cp + blockIdx.y,
                          items + (size_t)blockIdx.y * n_items, n_items, (int)blockIdx.x);
 }
 
@@ -1720,14 +1695,17 @@ hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *d
   const int grid = 8 * ((layer2_parts(D.H) * D.ntrain + 7) / 8) * (D.B / SLAB);
   const size_t sm = bwd_smem_bytes(bf16, D.H);
 #define CALL(BF, HH) \
-  hipLaunchKernelGGL((k_backward<BF, HH>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain)
+  hipLaunchKernelGGL((k_backward<BF, HH>), dim3(grid, n_seeds), dim3(512), sm, st, dD, a, c, D.B / SLAB, D.ntrain)
   DISPATCH_H(bf16, D.H, CALL);
 #undef CALL
   return hipGetLastError();
 }
-hipError_t launch_stage(const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a, const DevCtr *c,
-                        int n_seeds, hipStream_t st) {
-  hipLaunchKernelGGL(k_stage, dim3((D.B + 15) / 16, n_seeds), dim3(256), 0, st, dD, a, c);
+hipError_t launch_stage(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
+                        const DevCtr *c, int n_seeds, hipStream_t st) {
+  if (bf16)
+    hipLaunchKernelGGL(k_stage<true>, dim3((D.B + 15) / 16, n_seeds), dim3(256), 0, st, dD, a, c);
+  else
+    hipLaunchKernelGGL(k_stage<false>, dim3((D.B + 15) / 16, n_seeds), dim3(256), 0, st, dD, a, c);
   return hipGetLastError();
 }
 int strip_rows() { return USR; }
@@ -1737,13 +1715,13 @@ hipError_t launch_update(bool bf16, const TrainerDesc *dD, const DevArgs *a, Dev
   // n_items tiles + the misc block; a group launch pads grid.x to a multiple of 8
   const dim3 grid(n_seeds > 1 ? round_up(n_items + 1, 8) : n_items + 1, n_seeds);
   if (bf16 && n_seeds > 1)
-    hipLaunchKernelGGL((k_update<true, false>), grid, dim3(UT), 0, st, dD, a, c, items, n_items);
+    hipLaunchKernelGGL((k_update<true, false>), grid, dim3(256), 0, st, dD, a, c, items, n_items);
   else if (bf16)
-    hipLaunchKernelGGL((k_update<true, true>), grid, dim3(UT), 0, st, dD, a, c, items, n_items);
+    hipLaunchKernelGGL((k_update<true, true>), grid, dim3(512), 0, st, dD, a, c, items, n_items);
   else if (n_seeds > 1)
-    hipLaunchKernelGGL((k_update<false, false>), grid, dim3(UT), 0, st, dD, a, c, items, n_items);
+    hipLaunchKernelGGL((k_update<false, false>), grid, dim3(256), 0, st, dD, a, c, items, n_items);
   else
-    hipLaunchKernelGGL((k_update<false, true>), grid, dim3(UT), 0, st, dD, a, c, items, n_items);
+    hipLaunchKernelGGL((k_update<false, true>), grid, dim3(512), 0, st, dD, a, c, items, n_items);
   return hipGetLastError();
 }
 hipError_t launch_infer(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const FwdNet &N,

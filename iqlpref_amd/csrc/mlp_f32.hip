@@ -188,11 +188,23 @@ __global__ __launch_bounds__(256, 2) void k_mlp_f32(const MlpArgs M, const float
 #pragma unroll
         for (int m = 0; m < 4; ++m)
           a[m] = *reinterpret_cast<const uint4 *>(buf + (16 * m + r) * lda + 16 * ks + 4 * q);
+        // component-major issue order: the four MFMAs of one (n-tile, M-tile) pair accumulate into
+        // the same registers (40-cycle dependent latency vs 32-cycle issue); between two of them the
+        // wave issues the other 15 pairs
+        float4 af[4], bf[MAXT];
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-          if (live[t]) {
+        for (int m = 0; m < 4; ++m) af[m] = __builtin_bit_cast(float4, a[m]);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) P::mma(a[m], bq[t], acc[t][m]);
+        for (int t = 0; t < MAXT; ++t) bf[t] = __builtin_bit_cast(float4, bq[t]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int t = 0; t < MAXT; ++t) {
+            if (live[t]) {
+#pragma unroll
+              for (int m = 0; m < 4; ++m)
+                acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][c], bf[t][c], acc[t][m], 0, 0, 0);
+            }
           }
         }
 #pragma unroll
