@@ -71,6 +71,12 @@ typedef struct {
   int32_t row_stride; /* floats, multiple of 4                  */
   int32_t state_dim;
   int32_t action_dim;
+  uint64_t generation; /* changes whenever the CONTENTS of rows change (a Python ReplayBuffer
+                          bumps it on every load).  A call whose view equals the previous
+                          call's (rows, n_rows, generation), with on-device indices and no
+                          per-step outputs, continues that call: the batch its last step
+                          prefetched is used and nothing is re-sent.  0 is a valid value for
+                          callers that never rewrite rows in place.                        */
 } iqlhip_replay_view;
 
 /* Float offset of s' inside a row: S+A+2 rounded up to a multiple of 4; row stride (floats):

@@ -27,7 +27,7 @@ ERR_NOMEM = -4
 
 class ReplayView(C.Structure):
     _fields_ = [("rows", C.c_void_p), ("n_rows", C.c_int64), ("row_stride", C.c_int32),
-                ("state_dim", C.c_int32), ("action_dim", C.c_int32)]
+                ("state_dim", C.c_int32), ("action_dim", C.c_int32), ("generation", C.c_uint64)]
 
 
 class TrainerConfig(C.Structure):

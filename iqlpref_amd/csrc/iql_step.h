@@ -96,6 +96,7 @@ struct DevArgs {
   int64_t base_step;         // total_it of the first step of this call
   double lr_q, lr_v, lr_a_base;
   int64_t n_steps;           // steps of this call (bounds idx[] for the batch prefetch)
+  uint64_t generation;       // of the replay view (host-side bookkeeping: see push_args)
 };
 
 // Device-written counters / metrics.

@@ -763,6 +763,9 @@ __device__ __forceinline__ void loss_terms(const TrainerDesc &D, int net, const 
 // ========================================================================
 // k_backward
 //
+// (Tried: 512 threads, the dZ2 phase split over two groups of 8 rows.  The phase got 0.12 us
+// shorter, the load phase 0.7 us longer, the kernel 45 % slower at 8 seeds per launch: kept at 256.)
+//
 // One work-group = (trained net, 16-row slab, part of the dZ1 columns).  The W2^T stream is what
 // bounds this kernel (per-CU fetch rate from L2), so the H input features of layer 2 are split
 // into SPL parts of 64 (one 16-column tile per wave): every part redoes the cheap loss / dZ2
@@ -820,13 +823,10 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
 
   // ---- the loss inputs first: loads return in order, these must not queue behind the
   // weight stream requested next.  Thread (row tid / 16, lane16 = tid % 16). ----
-  // (512 threads: waves 0-3 own the loss lanes and the dZ1 GEMM, all eight share the dZ2 phase --
-  // a VALU chain per hidden unit that one wave per SIMD issued at half rate)
-  const bool lo4 = wave < 4;  // scalar
-  const int lrow = (tid & 255) >> 4, lj = tid & 15;
+  const int lrow = tid >> 4, lj = tid & 15;
   const int brow = slab * SLAB + lrow;
   float pv[FIN_NC][SPL];
-  if (lo4) {
+  {
     const float *o = g_outs + (size_t)brow * OUTW;
 #pragma unroll
     for (int c = 0; c < FIN_NC; ++c) {
@@ -836,15 +836,13 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
       for (int p = 0; p < SPL; ++p) pv[c][p] = ldg(o + ((unsigned)p * (unsigned)(B * OUTW) + cc));
     }
   }
-  float rew = 0.f, done = 0.f, actv[2] = {0.f, 0.f}, lsv[2] = {0.f, 0.f};
-  if (lo4) {
-    rew = ldg(g_rd + (size_t)brow * 2), done = ldg(g_rd + (size_t)brow * 2 + 1);
+  const float rew = ldg(g_rd + (size_t)brow * 2), done = ldg(g_rd + (size_t)brow * 2 + 1);
+  float actv[2], lsv[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {  // outputs lj and lj + 16 (A <= 32); clamped, unused beyond A
-      const int jc = lj + 16 * h < n_act ? lj + 16 * h : n_act - 1;
-      actv[h] = ldg(g_actf + (size_t)brow * n_act + jc);
-      lsv[h] = ldg(g_ls + jc);
-    }
+  for (int h = 0; h < 2; ++h) {  // outputs lj and lj + 16 (A <= 32); clamped, unused beyond A
+    const int jc = lj + 16 * h < n_act ? lj + 16 * h : n_act - 1;
+    actv[h] = ldg(g_actf + (size_t)brow * n_act + jc);
+    lsv[h] = ldg(g_ls + jc);
   }
   // keep these loads AHEAD of the weight stream (the scheduler otherwise moves some of them
   // behind it, and loads return in order)
@@ -852,11 +850,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   // ---- request everything else that does not depend on the loss, in the order it is
   // consumed: W3 and h2 for the dZ2 phase, then this part of W2^T for the GEMM, h1 for its
   // epilogue.  All unconditional (clamped). ----
-  // dZ2 phase: thread -> hidden unit c2 and (H = 256: 512 threads) one of two groups of 8 rows
-  constexpr int RG = H == 256 ? 2 : 1, RPT = SLAB / RG;  // row groups; rows per thread
-  const int c2 = (tid & 255) < H ? (tid & 255) : H - 1;
-  const int rg = RG == 2 ? (tid >> 8) : 0;
-  const bool dz2_on = (tid & 255) < H && (RG == 2 || tid < 256);
+  const int c2 = tid < H ? tid : H - 1;  // hidden unit this thread owns in the dZ2 phase
   // W3^T [H][out_pad]: this unit's weights to every output, 8 (bf16) / 4 (fp32) per 16-byte load
   constexpr int W3G = 32 / P::EPV;  // 16-byte groups covering 32 outputs
   uint4 w3q[W3G];
@@ -866,29 +860,29 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     for (int g = 0; g < W3G; ++g)
       if (g * P::EPV < out_pad) w3q[g] = ldg16(w3row + g * P::EPV);  // (scalar guard: no redundant loads)
   }
-  float h2v[RPT];
+  float h2v[16];
   {
     const T *h2T = g_hT + (size_t)(net * 2 + 1) * H * BP;
 #pragma unroll
-    for (int g4 = 0; g4 < RPT / 4; ++g4)
-      load4T<BF16>(h2T + fidx<P>(c2, slab * SLAB + RPT * rg + 4 * g4, nkb), &h2v[4 * g4]);
+    for (int g4 = 0; g4 < 4; ++g4)
+      load4T<BF16>(h2T + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), &h2v[4 * g4]);
   }
   __builtin_amdgcn_sched_barrier(0);
   uint4 w2t[K::NK2];
-  float h1v[4] = {0.f, 0.f, 0.f, 0.f};
-  if (lo4) {
+  {
     const T *W2Tw = reinterpret_cast<const T *>(p_w2ct) + (size_t)tile0 * K::NK2 * 64 * P::EPV;
 #pragma unroll
     for (int ks = 0; ks < K::NK2; ++ks) w2t[ks] = ldg16(W2Tw + ks * 64 * P::EPV + lane * P::EPV);
-    load4T<BF16>(g_hT + (size_t)(net * 2 + 0) * H * BP + fidx<P>(16 * tile0 + r, slab * SLAB + 4 * q, nkb), h1v);
   }
+  float h1v[4];
+  load4T<BF16>(g_hT + (size_t)(net * 2 + 0) * H * BP + fidx<P>(16 * tile0 + r, slab * SLAB + 4 * q, nkb), h1v);
   STAMP(1, 1);
 
   // ---- finish the forward outputs of this slab (sum of the parts, rounding, tanh) ----
 #pragma unroll
   for (int c = 0; c < FIN_NC; ++c) {
     const int col = lj + 16 * c;
-    if (lo4 && col < OUTW) {
+    if (col < OUTW) {
       float sum = pv[c][0];
 #pragma unroll
       for (int p = 1; p < SPL; ++p) sum += pv[c][p];
@@ -900,7 +894,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   __syncthreads();
 
   // ---- per-row loss terms and d(loss)/d(out)  (ref:581-637), LDS layout [j][16 rows] ----
-  if (lo4) {
+  {
     const float *f = fin + lrow * FIN_LD;
     LossIn lin;
     // TwinQ.forward = min(q1, q2) of the target critics (ref:531-533, 583-584); min over all E
@@ -937,18 +931,18 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     stg(g_lsp + (size_t)slab * n_act + j, s);
   }
   // d(out), feature-major, for the layer-3 weight gradient
-  for (int e = tid; part == 0 && e < out_dim * SLAB; e += 512) {
+  for (int e = tid; part == 0 && e < out_dim * SLAB; e += 256) {
     const int j = e / SLAB, rr = e - j * SLAB;
     stg(g_dz3T + (size_t)net * opmax * BP + fidx<P>(j, slab * SLAB + rr, nkb),
         P::from_f32(dz3[j * SLAB + rr]));
   }
 
   // ---- dZ2 = (dZ3 W3) * relu'(h2)   (VALU: K = out_dim <= 32) ----
-  if (dz2_on) {
+  if (tid < H) {
     T *dst = g_dz2T + (size_t)net * H * BP;
-    float s[RPT];
+    float s[SLAB];
 #pragma unroll
-    for (int rr = 0; rr < RPT; ++rr) s[rr] = 0.f;
+    for (int rr = 0; rr < SLAB; ++rr) s[rr] = 0.f;
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
       if (j < out_dim) {
@@ -964,8 +958,8 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
           w3j = fs[j % 4];
         }
 #pragma unroll
-        for (int g4 = 0; g4 < RPT / 4; ++g4) {
-          const float4 dv = *reinterpret_cast<const float4 *>(&dz3[j * SLAB + RPT * rg + 4 * g4]);
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float4 dv = *reinterpret_cast<const float4 *>(&dz3[j * SLAB + 4 * g4]);
           s[4 * g4] += dv.x * w3j, s[4 * g4 + 1] += dv.y * w3j;
           s[4 * g4 + 2] += dv.z * w3j, s[4 * g4 + 3] += dv.w * w3j;
         }
@@ -973,7 +967,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     }
     const bool mine = c2 / C::HQ == part;  // the part that owns this hidden unit stores its dZ2
 #pragma unroll
-    for (int g4 = 0; g4 < RPT / 4; ++g4) {
+    for (int g4 = 0; g4 < 4; ++g4) {
       float outv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -981,9 +975,9 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
         float sv = P::round(s[rr]);
         if (drop_on) sv = P::round(sv * drop_scale);
         outv[i] = h2v[rr] > 0.f ? sv : 0.f;
-        dz2s[(RPT * rg + rr) * HP + c2] = P::from_f32(outv[i]);
+        dz2s[rr * HP + c2] = P::from_f32(outv[i]);
       }
-      if (mine) store4T<BF16>(dst + fidx<P>(c2, slab * SLAB + RPT * rg + 4 * g4, nkb), outv);
+      if (mine) store4T<BF16>(dst + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), outv);
     }
   }
   __syncthreads();
@@ -996,7 +990,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   }
 
   // ---- dZ1 = (dZ2 W2) * relu'(h1)   (MFMA, B operand = transposed copy; one n-tile per wave) ----
-  if (lo4) {
+  {
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     const T *xrow = dz2s + r * HP + P::EPV * q;
 #pragma unroll
@@ -1577,7 +1571,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 // __global__ wrappers
 // ------------------------------------------------------------------------
 template <bool BF16, int H>
-__global__ __launch_bounds__(512) void k_backward(const TrainerDesc *__restrict__ Dp,
+__global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict__ Dp,
                                                   const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
                                                   const int nslab, const int ntrain) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1695,7 +1689,7 @@ hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *d
   const int grid = 8 * ((layer2_parts(D.H) * D.ntrain + 7) / 8) * (D.B / SLAB);
   const size_t sm = bwd_smem_bytes(bf16, D.H);
 #define CALL(BF, HH) \
-  hipLaunchKernelGGL((k_backward<BF, HH>), dim3(grid, n_seeds), dim3(512), sm, st, dD, a, c, D.B / SLAB, D.ntrain)
+  hipLaunchKernelGGL((k_backward<BF, HH>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain)
   DISPATCH_H(bf16, D.H, CALL);
 #undef CALL
   return hipGetLastError();

@@ -185,11 +185,16 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
 #pragma unroll
         for (int kk = 0; kk < KCH; ++kk) {
           if (ks0 + kk < nks) {
+            float4 bf[4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-              const uint4 b = *reinterpret_cast<const uint4 *>(wF + frag_off<P>(nt, ks0 + kk, nks, lane));
-              P::mma(a[kk], b, x[nt]);
-            }
+            for (int nt = 0; nt < 4; ++nt)
+              bf[nt] = *reinterpret_cast<const float4 *>(wF + frag_off<P>(nt, ks0 + kk, nks, lane));
+            const float4 af = __builtin_bit_cast(float4, a[kk]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt)
+                x[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], bf[nt][c], x[nt], 0, 0, 0);
           }
         }
       }
@@ -229,10 +234,18 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
       f32x4 kv[8];
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) kv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // component-major: the four K = 4 MFMAs of one fragment pair accumulate into the same
+      // registers; issuing the other seven n-tiles between them hides the dependent latency
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 4; ++ks) {
+        const float4 af = __builtin_bit_cast(float4, ha[ks]);
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) P::mma(ha[ks], wkv[nt][ks], kv[nt]);
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt)
+            kv[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], __builtin_bit_cast(float4, wkv[nt][ks])[c], kv[nt],
+                                                          0, 0, 0);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = 16 * mt + 4 * q + i;

@@ -158,6 +158,9 @@ def set_seed(seed: int, env=None, deterministic_torch: bool = False):
 # --------------------------------------------------------------------------- #
 # replay buffer (ref:164-226)
 # --------------------------------------------------------------------------- #
+_buffer_generation = [0]  # process-wide: every load of any buffer gets a fresh number
+
+
 class ReplayBuffer:
     """Device-resident replay buffer with packed rows [s|a|r|d|pad|s'|pad] (s' 16-byte aligned).
 
@@ -178,6 +181,7 @@ class ReplayBuffer:
         self._alloc(0)
         self._sample_calls = 0
         self._sample_seed = None
+        self._generation = 0
 
     def _alloc(self, n):
         S, A = self._state_dim, self._action_dim
@@ -227,11 +231,13 @@ class ReplayBuffer:
         torch.cuda.current_stream(self._dev).synchronize()  # the staging tensors die here
         self._size += n
         self._pointer = min(self._size, n)
+        _buffer_generation[0] += 1
+        self._generation = _buffer_generation[0]  # the contents changed: no prefetched batch survives
         print(f"Dataset size: {n}")
 
     def view(self) -> _lib.ReplayView:
         return _lib.ReplayView(ptr(self._rows), min(self._size, self._pointer), self._stride,
-                               self._state_dim, self._action_dim)
+                               self._state_dim, self._action_dim, self._generation)
 
     def sample(self, batch_size: int, indices: Optional[torch.Tensor] = None) -> TensorBatch:
         """ref:211-221.  Indices are drawn on device (Philox keyed by the torch seed

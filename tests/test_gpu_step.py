@@ -467,3 +467,54 @@ def test_trainer_lifecycle_does_not_leak(gh):
     torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB not returned after 40 trainers"
+
+
+def test_consecutive_calls_continue_each_other(gh):
+    """A call with the same replay view (rows, size, generation), on-device indices and no per-step
+    outputs continues the previous one: nothing is re-sent, the batch the last step prefetched is
+    used.  Bit-identical to one long call, to calls that do re-send (they return losses), and a
+    reloaded / different buffer is never served a stale batch."""
+    import iqlpref_amd as ia
+    d, hyper, data, nets = helpers.load_traj("traj_antmaze", "bf16")
+    B = hyper["batch"]
+    buf = gh.make_buffer(hyper, data)
+    one = gh.make_trainer(hyper, nets, "bf16", seed=11)
+    one.train_steps(buf, 21, B, return_losses=False, graph_unroll=0)
+    split = gh.make_trainer(hyper, nets, "bf16", seed=11)
+    for n, unroll in ((7, 0), (7, 7), (6, 3), (1, 0)):
+        split.train_steps(buf, n, B, return_losses=False, graph_unroll=unroll)
+    resend = gh.make_trainer(hyper, nets, "bf16", seed=11)
+    for n in (7, 7, 7):
+        resend.train_steps(buf, n, B, return_losses=True, graph_unroll=0)
+    for other in (split, resend):
+        assert torch.equal(one._params, other._params) and torch.equal(one._exp_avg_sq, other._exp_avg_sq)
+        assert torch.equal(one._target, other._target)
+    # another buffer (other contents, other generation) between two calls: its rows are sampled
+    data2 = {k: (np.asarray(v)[::-1].copy() if np.asarray(v).ndim else v) for k, v in data.items()}
+    buf2 = gh.make_buffer(hyper, data2)
+    assert buf2.view().generation != buf.view().generation
+    a, b = gh.make_trainer(hyper, nets, "bf16", seed=11), gh.make_trainer(hyper, nets, "bf16", seed=11)
+    a.train_steps(buf, 5, B, return_losses=False, graph_unroll=0)
+    a.train_steps(buf2, 5, B, return_losses=False, graph_unroll=0)
+    a.train_steps(buf, 5, B, return_losses=False, graph_unroll=0)
+    for bf in (buf, buf2, buf):
+        b.train_steps(bf, 5, B, return_losses=True, graph_unroll=0)
+    assert torch.equal(a._params, b._params)
+    c = gh.make_trainer(hyper, nets, "bf16", seed=11)
+    c.train_steps(buf, 15, B, return_losses=False, graph_unroll=0)
+    assert not torch.equal(a._params, c._params)  # (the second buffer did change the run)
+    # a group continues itself the same way
+    g1 = ia.SeedGroup([gh.make_trainer(hyper, nets, "bf16", seed=s) for s in (3, 4)])
+    g2 = ia.SeedGroup([gh.make_trainer(hyper, nets, "bf16", seed=s) for s in (3, 4)])
+    g1.train_steps(buf, 12, B, graph_unroll=4)
+    for n in (4, 4, 3, 1):
+        g2.train_steps(buf, n, B, graph_unroll=4)
+    for t1, t2 in zip(g1.trainers, g2.trainers):
+        assert torch.equal(t1._params, t2._params)
+    # ... and a member's own call in between does not leave the group with stale arguments
+    g2.trainers[0].train_steps(buf, 2, B, return_losses=False, graph_unroll=0)
+    g1.trainers[0].train_steps(buf, 2, B, return_losses=False, graph_unroll=0)
+    g1.train_steps(buf, 3, B, graph_unroll=0)
+    g2.train_steps(buf, 3, B, graph_unroll=0)
+    for t1, t2 in zip(g1.trainers, g2.trainers):
+        assert torch.equal(t1._params, t2._params)
