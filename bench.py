@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--min-timed-s", type=float, default=0.25,
                     help="the K-step block is repeated until this much timed work has accumulated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true",
+                    help="skip the long comparison region (rocprofv3 --pmc passes: its 60k queued dispatches "
+                         "overrun the profiler's intercepted queue)")
     ap.add_argument("--ensemble-q", type=int, default=4,
                     help="extra leg (N=1 only): BASELINE configs[4], an E-critic ensemble at batch 1024 "
                          "(same antmaze shapes); 0 disables.  Reported beside `value`, never as it")
@@ -341,7 +344,7 @@ def main():
         }
         if recs is not None:
             out["ranks"] = recs
-        if world == 1 and K < 5_000:
+        if world == 1 and K < 5_000 and not args.no_sustained:
             # the same path sustained over a long region, for comparison with the K-step blocks
             n_long = 20_000 // unroll * unroll
             torch.cuda.synchronize()

@@ -316,8 +316,8 @@ typedef struct {
   const float *q_wT;                 /* rows 0..63 of qkv_w, transposed [64][64]*/
   const float *attn_out_wT, *attn_out_b; /* attention.out_linear [64][64] T    */
   const float *ln1_w, *ln1_b;        /* layer_norm_1                           */
-  const float *mlp_in_wT, *mlp_in_b;   /* mlp.in_linear  [64][I] T, [I]        */
-  const float *mlp_out_wT, *mlp_out_b; /* mlp.out_linear [I][64] T, [64]       */
+  const float *mlp_in_w, *mlp_in_b;   /* mlp.in_linear.weight  [I][64], [I]   */
+  const float *mlp_out_w, *mlp_out_b; /* mlp.out_linear.weight [64][I], [64]  */
   const float *lnf_w, *lnf_b;        /* gpt.layer_norm                         */
   const float *pref_w_last;          /* LAST row of pref_linear.weight [64]    */
   float pref_b_last;                 /* last element of pref_linear.bias       */

@@ -63,7 +63,7 @@ class PtWeights(C.Structure):
                 [(n, C.c_void_p) for n in (
                     "state_wT", "state_b", "action_wT", "action_b", "temb", "sln_w", "sln_b",
                     "ln0_w", "ln0_b", "qkv_w", "qkv_b", "q_wT", "attn_out_wT", "attn_out_b",
-                    "ln1_w", "ln1_b", "mlp_in_wT", "mlp_in_b", "mlp_out_wT", "mlp_out_b",
+                    "ln1_w", "ln1_b", "mlp_in_w", "mlp_in_b", "mlp_out_w", "mlp_out_b",
                     "lnf_w", "lnf_b", "pref_w_last")] +
                 [("pref_b_last", C.c_float)])
 

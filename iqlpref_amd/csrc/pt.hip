@@ -18,8 +18,11 @@
 //               written V rows serve as the transposition scratch), B fragments (the K and V
 //               rows of attention.in_linear) live in 128 VGPRs for the whole kernel
 // Keys are stored as bf16 (ops.py:74-76 casts them), values as fp32.  The last token's query,
-// softmax over all keys (bf16 q.k products and scale as the reference), out projection, MLP,
-// final LayerNorm and value head stay on the vector units: one token per window.
+// softmax over all keys (bf16 q.k products and scale as the reference) and out projection stay on
+// the vector units: one token per window.  Its MLP does not: the post-attention residual and its
+// LayerNorm of PT_SLOTS consecutive windows are parked in LDS and the GPT2MLP, final LayerNorm and
+// value head then run once for all of them on the matrix cores (mlp_batch), so the MLP weights
+// are fetched once per PT_SLOTS windows instead of once per window.
 #include "../../include/iqlhip.h"
 #include "common.h"
 
@@ -28,6 +31,7 @@ namespace iqlhip {
 constexpr int E = 64;
 constexpr int PT_WAVES = 8;
 constexpr int VLD = E + 4;  // row stride of the V rows (floats): conflict-free A-fragment reads
+constexpr int PT_SLOTS = 8; // windows whose last-token MLP is batched (= PT_WAVES: one final LayerNorm per wave)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -95,9 +99,11 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
   float *ovec = hlast + E;                                               // [64] attention output / LN1 output
   float *part = ovec + E;                                                // [PT_WAVES][64] cross-wave partials
   float *stat = part + PT_WAVES * E;                                     // [PT_WAVES][16 heads] x 2
-  float *hid = stat + 2 * PT_WAVES * 16;                                 // [I]
-  float *lg = hid + I;                                                   // [Tmax][NH] logits
-  float *fvec = lg + (size_t)Tmax * NH;                                  // [6][64] per-feature vectors
+  float *lg = stat + 2 * PT_WAVES * 16;                                  // [Tmax][NH] logits
+  float *fvec = lg + round_up(Tmax * NH, 4);                             // [6][64] per-feature vectors
+  float *pend_x = fvec + 6 * E;                                          // [PT_SLOTS][64] x1 of parked windows
+  float *pend_h = pend_x + PT_SLOTS * E;                                 // [PT_SLOTS][VLD] LN1(x1)
+  float *hidb = pend_h + PT_SLOTS * VLD;                                 // [PT_SLOTS][I + 4] MLP hidden
 
   // ---- weights that stay on chip for the whole queue ----
   // embedding weights as MFMA B fragments (common.h fidx): element (feature f, input k), zero padded
@@ -131,11 +137,90 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
   const float l1w = W.ln1_w[lane], l1b = W.ln1_b[lane];
   const float lfw = W.lnf_w[lane], lfb = W.lnf_b[lane];
   const float bq = W.qkv_b[lane];
-  const float bo = W.attn_out_b[lane], bmo = W.mlp_out_b[lane];
+  const float bo = W.attn_out_b[lane];
   const float pw = W.pref_w_last[lane];
   const float eps = W.eps;
   const float inv_sqrt_hd = 1.0f / sqrtf((float)HD);
   __syncthreads();
+
+  // ---- GPT2MLP + residual + final LayerNorm + value head of the parked tokens (slots < n) ----
+  // hidden = relu(h1 . Win^T + b): [16 x 64] . [64 x I], slots are the M rows (rows >= PT_SLOTS
+  // alias rows 0..7: their results are dropped); the wave's n-tiles are I / 16 / PT_WAVES apart.
+  // x2 = x1 + hidden . Wout^T + b: [16 x I] . [I x 64], one 16-feature n-tile per wave 0..3.
+  // B fragments come straight from the torch-layout weights ([out][in]: 16 B per lane).
+  const int ldh = I + 4;
+  auto mlp_batch = [&](int n, int64_t first) {
+    __syncthreads();  // pend_x / pend_h of every slot written
+    {
+      f32x4 ha[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        ha[ks] = *reinterpret_cast<const f32x4 *>(pend_h + (r & (PT_SLOTS - 1)) * VLD + 16 * ks + 4 * q);
+      for (int nt0 = wave; nt0 < I / 16; nt0 += 2 * PT_WAVES) {
+        // two n-tiles per pass: independent accumulators hide the dependent MFMA latency
+        const int nt1 = nt0 + PT_WAVES;
+        const bool two = nt1 < I / 16;
+        uint4 b0[4], b1[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          b0[ks] = ldg16(W.mlp_in_w + (size_t)(16 * nt0 + r) * E + 16 * ks + 4 * q);
+          b1[ks] = ldg16(W.mlp_in_w + (size_t)(16 * (two ? nt1 : nt0) + r) * E + 16 * ks + 4 * q);
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ks][c], __builtin_bit_cast(float4, b0[ks])[c], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ks][c], __builtin_bit_cast(float4, b1[ks])[c], acc1, 0, 0, 0);
+          }
+        if (q < PT_SLOTS / 4) {
+          const float bi0 = W.mlp_in_b[16 * nt0 + r], bi1 = W.mlp_in_b[16 * (two ? nt1 : nt0) + r];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            hidb[(4 * q + i) * ldh + 16 * nt0 + r] = fmaxf(acc0[i] + bi0, 0.f);
+            if (two) hidb[(4 * q + i) * ldh + 16 * nt1 + r] = fmaxf(acc1[i] + bi1, 0.f);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (wave < 4) {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const float *wrow = W.mlp_out_w + (size_t)(16 * wave + r) * I + 4 * q;
+      const float *arow = hidb + (r & (PT_SLOTS - 1)) * ldh + 4 * q;
+      for (int ks0 = 0; ks0 < I / 16; ks0 += 8) {
+        uint4 bfr[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) bfr[kk] = ldg16(wrow + 16 * (ks0 + kk));
+#pragma unroll
+        for (int kk = 0; kk < 8; kk += 2) {
+          const f32x4 a0 = *reinterpret_cast<const f32x4 *>(arow + 16 * (ks0 + kk));
+          const f32x4 a1 = *reinterpret_cast<const f32x4 *>(arow + 16 * (ks0 + kk + 1));
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], __builtin_bit_cast(float4, bfr[kk])[c], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], __builtin_bit_cast(float4, bfr[kk + 1])[c], acc1, 0, 0, 0);
+          }
+        }
+      }
+      if (q < PT_SLOTS / 4) {
+        const float bo2 = W.mlp_out_b[16 * wave + r];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          part[(4 * q + i) * E + 16 * wave + r] = (acc0[i] + acc1[i]) + bo2 + pend_x[(4 * q + i) * E + 16 * wave + r];
+      }
+    }
+    __syncthreads();
+    if (wave < n) {  // PT_SLOTS == PT_WAVES: slot = wave, feature = lane
+      const float y = layer_norm(part[wave * E + lane], lfw, lfb, eps);  // gpt.layer_norm
+      const float v = wave_sum(y * pw) + W.pref_b_last;
+      if (lane == 0) out[first + (int64_t)wave * gridDim.x] = v;
+    }
+    __syncthreads();  // LDS is reused by the next window
+  };
+  int nslot = 0;
+  int64_t batch_first = 0;
 
   for (int64_t win = blockIdx.x; win < n_win; win += gridDim.x) {
     const int64_t start = win_start[win];
@@ -299,35 +384,16 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
 #pragma unroll 8
     for (int j = 0; j < E; ++j) x1 += ovec[j] * woT[j * E + lane];
     const float h1 = layer_norm(x1, l1w, l1b, eps);
-    __syncthreads();  // everyone has read ovec
-    if (wave == 0) ovec[lane] = h1;
-    __syncthreads();
-    // ---- MLP: hidden units j = lane + 64 m, m split over the waves ----
-    for (int m = wave; m < I / E; m += PT_WAVES) {
-      const int j = lane + E * m;
-      float acc = W.mlp_in_b[j];
-#pragma unroll 8
-      for (int e = 0; e < E; ++e) acc += ovec[e] * W.mlp_in_wT[(size_t)e * I + j];
-      hid[j] = fmaxf(acc, 0.f);
+    // park the token: its MLP runs with the other slots' (mlp_batch below)
+    if (wave == 0) pend_x[nslot * E + lane] = x1, pend_h[nslot * VLD + lane] = h1;
+    if (nslot == 0) batch_first = win;
+    ++nslot;
+    if (nslot == PT_SLOTS || win + (int64_t)gridDim.x >= n_win) {
+      mlp_batch(nslot, batch_first);
+      nslot = 0;
+    } else {
+      __syncthreads();  // LDS is reused by the next window
     }
-    __syncthreads();
-    {
-      const int j0 = wave * (I / PT_WAVES), j1 = j0 + I / PT_WAVES;
-      float acc = 0.f;
-#pragma unroll 8
-      for (int j = j0; j < j1; ++j) acc += hid[j] * W.mlp_out_wT[(size_t)j * E + lane];
-      part[wave * E + lane] = acc;
-    }
-    __syncthreads();
-    if (wave == 0) {
-      float x2 = bmo + x1;
-#pragma unroll
-      for (int w = 0; w < PT_WAVES; ++w) x2 += part[w * E + lane];
-      const float y = layer_norm(x2, lfw, lfb, eps);  // gpt.layer_norm
-      const float v = wave_sum(y * pw) + W.pref_b_last;
-      if (lane == 0) out[win] = v;
-    }
-    __syncthreads();  // LDS is reused by the next window
   }
 }
 
@@ -335,7 +401,8 @@ size_t pt_smem_bytes(const iqlhip_pt_weights &W, int ql) {
   const size_t Tmax = 2 * (size_t)ql;
   const size_t ks = (size_t)round_up(W.state_dim, 16) + round_up(W.action_dim, 16);
   return Tmax * VLD * 4 + Tmax * E * 2 + ks * E * 4 + 2 * E * E * 4 +
-         (3 * E + PT_WAVES * E + 2 * PT_WAVES * 16 + W.inter_dim + Tmax * W.num_heads + 6 * E) * 4 + 64;
+         (3 * E + PT_WAVES * E + 2 * PT_WAVES * 16 + round_up((int)Tmax * W.num_heads, 4) + 6 * E + PT_SLOTS * E +
+          PT_SLOTS * VLD + PT_SLOTS * (W.inter_dim + 4)) * 4 + 64;
 }
 
 hipError_t launch_pt(const iqlhip_pt_weights &W, const float *obs, const float *act, int64_t n_rows,

@@ -559,8 +559,8 @@ class RewardPT(nn.Module):
             q_wT=f(blk.attention.in_linear.weight[:self.state_linear.out_features].t()),
             attn_out_wT=f(blk.attention.out_linear.weight.t()), attn_out_b=f(blk.attention.out_linear.bias),
             ln1_w=f(blk.layer_norm_1.weight), ln1_b=f(blk.layer_norm_1.bias),
-            mlp_in_wT=f(blk.mlp.in_linear.weight.t()), mlp_in_b=f(blk.mlp.in_linear.bias),
-            mlp_out_wT=f(blk.mlp.out_linear.weight.t()), mlp_out_b=f(blk.mlp.out_linear.bias),
+            mlp_in_w=f(blk.mlp.in_linear.weight), mlp_in_b=f(blk.mlp.in_linear.bias),
+            mlp_out_w=f(blk.mlp.out_linear.weight), mlp_out_b=f(blk.mlp.out_linear.bias),
             lnf_w=f(self.gpt.layer_norm.weight), lnf_b=f(self.gpt.layer_norm.bias),
             pref_w_last=f(self.pref_linear.weight[-1]))
         w = _lib.PtWeights()

@@ -10,16 +10,20 @@ OUT=$PWD/gpurun_out/prof_$TAG
 ARGS="--no-cpu-baseline --no-relabel --agents-per-gpu 0 --ensemble-q 0 --min-timed-s 0.05"
 mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 3000 --warmup 300 $ARGS > $OUT/trace.json
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 3000 --warmup 300 $ARGS > $OUT/trace.json
 echo "trace done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python bench.py --steps 500 --warmup 100 $ARGS > $OUT/fetch.json
+# counter passes: short regions only (a counter pass serialises every dispatch and the profiler's
+# intercepted queue holds 16k packets: the 20,000-step `sustained` region overran it in r2m)
+PMC="--steps 500 --warmup 100 --no-sustained $ARGS"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python bench.py $PMC > $OUT/fetch.json
 echo "fetch done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python bench.py --steps 500 --warmup 100 $ARGS > $OUT/write.json
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python bench.py $PMC > $OUT/write.json
 echo "write done"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -- python bench.py --steps 500 --warmup 100 $ARGS > $OUT/mfma.json || echo "mfma pass failed (counter set not available)"
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -- python bench.py $PMC > $OUT/mfma.json
+echo "mfma done"
 python tools/pmc_summary.py $OUT/fetch 1 $OUT/pmc_fetch_size.json > /dev/null
 python tools/pmc_summary.py $OUT/write 1 $OUT/pmc_write_size.json > /dev/null
-python tools/pmc_summary.py $OUT/mfma 1 $OUT/pmc_mfma.json > /dev/null || true
+python tools/pmc_summary.py $OUT/mfma 1 $OUT/pmc_mfma.json > /dev/null
 python tools/traffic_json.py $OUT/pmc_fetch_size.json $OUT/pmc_write_size.json $OUT/traffic.json
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 # keep only the summaries (the raw per-dispatch CSVs are tens of MB)
