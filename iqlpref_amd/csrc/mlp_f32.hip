@@ -72,13 +72,24 @@ __device__ __forceinline__ float act_flax(float v, int i) {
     default: return v;
   }
 }
+// The kernel is instantiated per activation family (ACT: 0 relu hidden layers, 1 tanh hidden layers,
+// 2 anything of the table above).  The epilogues are unrolled 64-fold over register tiles: with the
+// whole table inlined at every site the kernel was 0.5 MB of code and every site an instruction-cache
+// miss (the relu path spent more time there than in its MFMAs).  The table variant therefore writes
+// raw sums to LDS and applies the activation in ONE rolled pass.
+template <int ACT>
 __device__ __forceinline__ float act_apply(float v, int kind) {  // hidden layers
+  if constexpr (ACT == 0) return fmaxf(v, 0.f);
+  if constexpr (ACT == 1) return tanhf(v);
   return kind >= 8 ? act_flax(v, kind - 8) : (kind == 0 ? fmaxf(v, 0.f) : tanhf(v));
 }
+template <int ACT>
 __device__ __forceinline__ float out_apply(float v, int kind) {  // output layer
+  if constexpr (ACT != 2) return kind == 1 ? tanhf(v) : v;
   return kind >= 8 ? act_flax(v, kind - 8) : (kind == 1 ? tanhf(v) : v);
 }
 
+template <int ACT>
 __global__ __launch_bounds__(256, 2) void k_mlp_f32(const MlpArgs M, const float *__restrict__ x, int64_t n,
                                                     int x_stride, float *__restrict__ out, int out_stride) {
   using P = Prec<false>;
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_f32(const MlpArgs M, const float
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int rr = 16 * m + 4 * (ln >> 4) + i;
-            if (row0 + rr < n) stg(out + (size_t)(row0 + rr) * out_stride + ncol, out_apply(sum[i] + bvv, M.out_act));
+            if (row0 + rr < n) stg(out + (size_t)(row0 + rr) * out_stride + ncol, out_apply<ACT>(sum[i] + bvv, M.out_act));
           }
         }
       }
@@ -222,15 +233,31 @@ __global__ __launch_bounds__(256, 2) void k_mlp_f32(const MlpArgs M, const float
         for (int i = 0; i < 4; ++i) {
           const int rr = 16 * m + 4 * q + i;
           float v = acc[t][m][i] + bv[t];
-          if (!last) {
-            buf[rr * lda + ncol] = ncol < N ? act_apply(v, M.hidden_act) : 0.f;  // zero K padding
+          if constexpr (ACT == 2) {
+            buf[rr * lda + ncol] = v;  // raw: the table is applied in the rolled pass below
+          } else if (!last) {
+            buf[rr * lda + ncol] = ncol < N ? act_apply<ACT>(v, M.hidden_act) : 0.f;  // zero K padding
           } else if (ncol < N && row0 + rr < n) {
-            stg(out + (size_t)(row0 + rr) * out_stride + ncol, out_apply(v, M.out_act));
+            stg(out + (size_t)(row0 + rr) * out_stride + ncol, out_apply<ACT>(v, M.out_act));
           }
         }
       }
     }
     __syncthreads();
+    if constexpr (ACT == 2) {
+      const int Np = 16 * ntile;
+#pragma unroll 1
+      for (int e = tid; e < MROWS * Np; e += 256) {
+        const int rr = e / Np, c = e - rr * Np;
+        const float v = buf[rr * lda + c];
+        if (!last) {
+          buf[rr * lda + c] = c < N ? act_apply<2>(v, M.hidden_act) : 0.f;
+        } else if (c < N && row0 + rr < n) {
+          stg(out + (size_t)(row0 + rr) * out_stride + c, out_apply<2>(v, M.out_act));
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -265,11 +292,13 @@ hipError_t launch_mlp_f32(const iqlhip_mlp_desc &d, const float *x, int64_t n, i
   const int nt_last = round_up(d.dims[d.n_layers], 16) / 16;
   if (nt_last < 4 && sm < (size_t)4 * nt_last * 4 * 64 * 16) sm = (size_t)4 * nt_last * 4 * 64 * 16;
   // (set on every call: the attribute is per device, and a process may drive several)
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_f32), hipFuncAttributeMaxDynamicSharedMemorySize,
+  const int act = (d.hidden_act >= 8 || d.out_act >= 8) ? 2 : d.hidden_act;  // instantiation, see act_apply
+  auto kern = act == 0 ? k_mlp_f32<0> : act == 1 ? k_mlp_f32<1> : k_mlp_f32<2>;
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                           160 * 1024);
   if (e == hipSuccess) {
     const int64_t grid = (n + MROWS - 1) / MROWS;
-    hipLaunchKernelGGL(k_mlp_f32, dim3((unsigned)grid), dim3(256), sm, st, M, x, n, x_stride, out, out_stride);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), sm, st, M, x, n, x_stride, out, out_stride);
     e = hipGetLastError();
   }
   (void)hipFreeAsync(wf, st);

@@ -25,6 +25,7 @@
 // are fetched once per PT_SLOTS windows instead of once per window.
 #include "../../include/iqlhip.h"
 #include "common.h"
+#include <cstdlib>
 
 namespace iqlhip {
 
@@ -77,8 +78,14 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
                                                                const int64_t *__restrict__ win_start,
                                                                const int32_t *__restrict__ win_len,
                                                                const int32_t *__restrict__ win_t0,
-                                                               int64_t n_win, int ql, float *__restrict__ out) {
+                                                               int64_t n_win, int ql, float *__restrict__ out,
+                                                               int skip_arg) {
   using P = Prec<false>;
+#ifdef IQL_STAMPS
+  const int skip = skip_arg;  // diagnostic builds: bit mask of phases left out (results are wrong)
+#else
+  constexpr int skip = 0;
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
       for (int i = 0; i < 4; ++i) {
         const int k = 16 * mt + 4 * q + i < len ? 16 * mt + 4 * q + i : len - 1;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) x[nt][i] = ldg(W.temb + (size_t)(t0 + k) * E + 16 * nt + r);
+        for (int nt = 0; nt < 4; ++nt) x[nt][i] = (skip & 4) ? 0.5f : ldg(W.temb + (size_t)(t0 + k) * E + 16 * nt + r);
       }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const int k = 16 * (ks0 + kk) + 4 * q + c;
-            const float xv = ldg(rowp + (k < D ? k : D - 1));
+            const float xv = (skip & 4) ? 0.25f : ldg(rowp + (k < D ? k : D - 1));
             v[c] = k < D ? xv : 0.f;
           }
           a[kk] = __builtin_bit_cast(uint4, make_float4(v[0], v[1], v[2], v[3]));
@@ -286,11 +293,11 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
       float lw[4], lb[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) lw[nt] = fvec[2 * E + 16 * nt + r], lb[nt] = fvec[3 * E + 16 * nt + r];
-      layer_norm_tile(x, lw, lb, eps);  // stacked_layer_norm
+      if (!(skip & 2)) layer_norm_tile(x, lw, lb, eps);  // stacked_layer_norm
       f32x4 h[4] = {x[0], x[1], x[2], x[3]};
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) lw[nt] = fvec[4 * E + 16 * nt + r], lb[nt] = fvec[5 * E + 16 * nt + r];
-      layer_norm_tile(h, lw, lb, eps);  // block pre-LN
+      if (!(skip & 2)) layer_norm_tile(h, lw, lb, eps);  // block pre-LN
       // the window's last token (action token len - 1) feeds the query / residual path
       if (kind == 1 && mt == nmt - 1) {
 #pragma unroll
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
       // component-major: the four K = 4 MFMAs of one fragment pair accumulate into the same
       // registers; issuing the other seven n-tiles between them hides the dependent latency
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < ((skip & 16) ? 0 : 4); ++ks) {
         const float4 af = __builtin_bit_cast(float4, ha[ks]);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = 16 * mt + 4 * q + i;
-        if (k < len) {
+        if (k < len && !(skip & 8)) {
           const int t = 2 * k + kind;
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
@@ -346,6 +353,10 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
     }
     __syncthreads();
     // ================= last token: query, attention over all keys =================
+    if (skip & 1) {
+      if (tid == 0) out[win] = 0.f;
+      continue;
+    }
     float qv = bq;
 #pragma unroll 8
     for (int j = 0; j < E; ++j) qv += hlast[j] * wqT[j * E + lane];
@@ -419,8 +430,12 @@ hipError_t launch_pt(const iqlhip_pt_weights &W, const float *obs, const float *
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pt_relabel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
+  int skip = 0;
+#ifdef IQL_STAMPS
+  if (const char *sk = getenv("IQLHIP_PT_SKIP")) skip = atoi(sk);
+#endif
   hipLaunchKernelGGL(k_pt_relabel, dim3((unsigned)grid), dim3(64 * PT_WAVES), sm, st, W, obs, act, n_rows,
-                     win_start, win_len, win_t0, n_win, ql, out);
+                     win_start, win_len, win_t0, n_win, ql, out, skip);
   return hipGetLastError();
 }
 
