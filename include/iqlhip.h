@@ -313,8 +313,7 @@ typedef struct {
   const float *sln_w, *sln_b;        /* stacked_layer_norm                     */
   const float *ln0_w, *ln0_b;        /* gpt.layers.0.layer_norm_0              */
   const float *qkv_w, *qkv_b;        /* attention.in_linear [192][64], [192]   */
-  const float *q_wT;                 /* rows 0..63 of qkv_w, transposed [64][64]*/
-  const float *attn_out_wT, *attn_out_b; /* attention.out_linear [64][64] T    */
+  const float *attn_out_w, *attn_out_b; /* attention.out_linear.weight [64][64], [64] */
   const float *ln1_w, *ln1_b;        /* layer_norm_1                           */
   const float *mlp_in_w, *mlp_in_b;   /* mlp.in_linear.weight  [I][64], [I]   */
   const float *mlp_out_w, *mlp_out_b; /* mlp.out_linear.weight [64][I], [64]  */

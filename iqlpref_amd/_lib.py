@@ -17,7 +17,7 @@ N_TENSORS = 6 * (MAX_CRITICS + 2) + 1
 MLP_MAX_LAYERS = 8
 MAX_GROUP = 16
 ACT_FLAX_BASE = 8  # iqlhip_mlp_desc activation code 8 + i = entry i of reward_models/q_mlp.py:121-130
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ERR_INVALID = -1
 ERR_HIP = -2
@@ -62,7 +62,7 @@ class PtWeights(C.Structure):
                  ("n_temb", C.c_int32), ("eps", C.c_float)] +
                 [(n, C.c_void_p) for n in (
                     "state_wT", "state_b", "action_wT", "action_b", "temb", "sln_w", "sln_b",
-                    "ln0_w", "ln0_b", "qkv_w", "qkv_b", "q_wT", "attn_out_wT", "attn_out_b",
+                    "ln0_w", "ln0_b", "qkv_w", "qkv_b", "attn_out_w", "attn_out_b",
                     "ln1_w", "ln1_b", "mlp_in_w", "mlp_in_b", "mlp_out_w", "mlp_out_b",
                     "lnf_w", "lnf_b", "pref_w_last")] +
                 [("pref_b_last", C.c_float)])

@@ -77,7 +77,7 @@ static int fail(int code, const char *fmt, ...) {
   } while (0)
 
 extern "C" const char *iqlhip_last_error(void) { return g_err; }
-extern "C" int iqlhip_abi_version(void) { return 3; }
+extern "C" int iqlhip_abi_version(void) { return 4; }
 // sha256 prefix of csrc/* + include/iqlhip.h, stamped by iqlpref_amd/build.py: the Python side
 // refuses a library whose tag does not match the sources it sits beside
 #ifndef IQLHIP_BUILD_TAG

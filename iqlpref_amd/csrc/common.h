@@ -97,6 +97,51 @@ struct Prec<false> {
   }
 };
 
+// ---- cross-lane sums without the LDS crossbar ----
+// __shfl_xor compiles to ds_bpermute_b32 (an LDS-pipe round trip, >100 cycles, and a butterfly
+// is a chain of them).  Within a row of 16 lanes the DPP permutes are plain VALU operands; across
+// rows gfx950 has v_permlane16_swap / v_permlane32_swap.  (The clang of ROCm 7.2 returns the
+// wrong register for the second result of __builtin_amdgcn_permlane*_swap: inline asm instead.)
+template <int CTRL, class T>
+__device__ __forceinline__ T dpp_mov(T v) {
+  static_assert(sizeof(T) == 4, "32-bit lanes");
+  return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <class T>
+__device__ __forceinline__ T xor16_sum(T v) {  // v[lane] + v[lane ^ 16]
+  T a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+template <class T>
+__device__ __forceinline__ T xor32_sum(T v) {  // v[lane] + v[lane ^ 32]
+  T a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+// sum over aligned groups of W consecutive lanes (W a power of two <= 64), result in every lane
+template <int W, class T>
+__device__ __forceinline__ T lane_sum(T v) {
+  if constexpr (W >= 2) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  if constexpr (W >= 4) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  if constexpr (W >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror (quads already uniform)
+  if constexpr (W >= 16) v += dpp_mov<0x140>(v);  // row_mirror (halves already uniform)
+  if constexpr (W >= 32) v = xor16_sum(v);
+  if constexpr (W >= 64) v = xor32_sum(v);
+  return v;
+}
+// the same for a wave-uniform run-time width
+template <class T>
+__device__ __forceinline__ T lane_sum_rt(T v, int w) {
+  if (w >= 2) v += dpp_mov<0xB1>(v);
+  if (w >= 4) v += dpp_mov<0x4E>(v);
+  if (w >= 8) v += dpp_mov<0x141>(v);
+  if (w >= 16) v += dpp_mov<0x140>(v);
+  if (w >= 32) v = xor16_sum(v);
+  if (w >= 64) v = xor32_sum(v);
+  return v;
+}
+
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // Fragment-major layout of an [F][K] operand matrix (F padded to 16, K to KM).

@@ -51,8 +51,7 @@ __global__ __launch_bounds__(COLS *L) void k_cvar(const float *__restrict__ pred
       const uint4 v = *reinterpret_cast<const uint4 *>(col + k);
       cnt += (v.x <= mid ? 1 : 0) + (v.y <= mid ? 1 : 0) + (v.z <= mid ? 1 : 0) + (v.w <= mid ? 1 : 0);
     }
-#pragma unroll
-    for (int m = L >> 1; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m);
+    cnt = lane_sum<L>(cnt);
     if (lo < hi) {
       if (cnt >= n_tail)
         hi = mid;
@@ -70,8 +69,7 @@ __global__ __launch_bounds__(COLS *L) void k_cvar(const float *__restrict__ pred
     for (int e = 0; e < 4; ++e)
       if (kk[e] < lo) sum += key2f(kk[e]), ++less;
   }
-#pragma unroll
-  for (int m = L >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, m), less += __shfl_xor(less, m);
+  sum = lane_sum<L>(sum), less = lane_sum<L>(less);
   if (p == 0 && col0 + c < N) out[col0 + c] = (sum + (float)(n_tail - less) * thr) / (float)n_tail;
 }
 

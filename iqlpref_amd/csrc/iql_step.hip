@@ -1315,8 +1315,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       if (th + UWPO * tb < nit)
         *reinterpret_cast<f32x4 *>(&tile[(16 * wo + r) * TLD + 16 * (th + UWPO * tb) + 4 * q]) = acc[tb];
     if (th == 0) {
-      bsum += __shfl_xor(bsum, 16);
-      bsum += __shfl_xor(bsum, 32);
+      bsum = xor32_sum(xor16_sum(bsum));
       if (q == 0) bgrad[16 * wo + r] = bsum;
     }
     __syncthreads();
@@ -1492,8 +1491,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 #pragma unroll
     for (int b = 0; b < UNB; ++b) {
       float bs = bsum[b];
-      bs += __shfl_xor(bs, 16);
-      bs += __shfl_xor(bs, 32);
+      bs = xor32_sum(xor16_sum(bs));
       if (q == 0) bgrad[16 * UNB * wo + 16 * b + r] = bs;
     }
   }

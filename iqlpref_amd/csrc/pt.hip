@@ -17,12 +17,15 @@
 //   K | V       [16 x 64] . Wkv^T (64 -> 128): A fragments through LDS (the job's own, not yet
 //               written V rows serve as the transposition scratch), B fragments (the K and V
 //               rows of attention.in_linear) live in 128 VGPRs for the whole kernel
-// Keys are stored as bf16 (ops.py:74-76 casts them), values as fp32.  The last token's query,
-// softmax over all keys (bf16 q.k products and scale as the reference) and out projection stay on
-// the vector units: one token per window.  Its MLP does not: the post-attention residual and its
-// LayerNorm of PT_SLOTS consecutive windows are parked in LDS and the GPT2MLP, final LayerNorm and
-// value head then run once for all of them on the matrix cores (mlp_batch), so the MLP weights
-// are fetched once per PT_SLOTS windows instead of once per window.
+// Keys are stored as bf16 (ops.py:74-76 casts them), values as fp32.  The job that holds the
+// window's last action token also projects its tile's queries (one more [16 x 64] . [64 x 64] on
+// the matrix cores) and leaves the last token's query (bf16-rounded, ops.py:74) and residual
+// stream in LDS.  Per window only the attention of that one query stays on the vector units:
+// logits over all keys (bf16 q.k products and scale as the reference), softmax, P.V.  Everything
+// behind it -- attention out projection, residual, LayerNorm 1, GPT2MLP, residual, final
+// LayerNorm, value head -- is parked per window and runs once per PT_SLOTS windows on the matrix
+// cores (tail_batch), so those weights are fetched once per PT_SLOTS windows.
+// Cross-lane sums are DPP / v_permlane*_swap (common.h lane_sum), not ds_bpermute.
 #include "../../include/iqlhip.h"
 #include "common.h"
 #include <cstdlib>
@@ -34,20 +37,9 @@ constexpr int PT_WAVES = 8;
 constexpr int VLD = E + 4;  // row stride of the V rows (floats): conflict-free A-fragment reads
 constexpr int PT_SLOTS = 8; // windows whose last-token MLP is batched (= PT_WAVES: one final LayerNorm per wave)
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  return v;
-}
-__device__ __forceinline__ float seg_sum(float v, int width) {  // lanes grouped by `width` (pow2)
-  for (int m = width >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  return v;
-}
-__device__ __forceinline__ float sum16(float v) {  // over the 16 lanes that share lane >> 4
-#pragma unroll
-  for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return lane_sum<64>(v); }
+__device__ __forceinline__ float seg_sum(float v, int width) { return lane_sum_rt(v, width); }  // pow2 groups
+__device__ __forceinline__ float sum16(float v) { return lane_sum<16>(v); }  // the 16 lanes sharing lane >> 4
 // LayerNorm over the 64 lanes (flax/torch: biased variance, eps inside the sqrt)
 __device__ __forceinline__ float layer_norm(float x, float w, float b, float eps) {
   const float mu = wave_sum(x) * (1.0f / E);
@@ -99,17 +91,15 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
   uint16_t *Kb = reinterpret_cast<uint16_t *>(Vs + (size_t)Tmax * VLD);  // [Tmax][64] bf16
   float *wsF = reinterpret_cast<float *>(Kb + (size_t)Tmax * E);         // fragment-major [64][16 nks_s]
   float *waF = wsF + nks_s * 16 * E;                                     // fragment-major [64][16 nks_a]
-  float *wqT = waF + nks_a * 16 * E;                                     // [64][64]
-  float *woT = wqT + E * E;                                              // [64][64]
-  float *xlast = woT + E * E;                                            // [64]
-  float *hlast = xlast + E;                                              // [64]
-  float *ovec = hlast + E;                                               // [64] attention output / LN1 output
-  float *part = ovec + E;                                                // [PT_WAVES][64] cross-wave partials
+  float *wvF = waF + nks_a * 16 * E;                                     // [4 nt][4 ks][64 lanes][4] value projection
+  float *qlast = wvF + 4 * 4 * 64 * 4;                                   // [64] last token's query (bf16 values)
+  float *part = qlast + E;                                               // [PT_WAVES][64] cross-wave partials
   float *stat = part + PT_WAVES * E;                                     // [PT_WAVES][16 heads] x 2
   float *lg = stat + 2 * PT_WAVES * 16;                                  // [Tmax][NH] logits
   float *fvec = lg + round_up(Tmax * NH, 4);                             // [6][64] per-feature vectors
-  float *pend_x = fvec + 6 * E;                                          // [PT_SLOTS][64] x1 of parked windows
-  float *pend_h = pend_x + PT_SLOTS * E;                                 // [PT_SLOTS][VLD] LN1(x1)
+  float *pend_x = fvec + 6 * E;                                          // [PT_SLOTS][64] residual stream of parked windows
+  float *pend_o = pend_x + PT_SLOTS * E;                                 // [PT_SLOTS][VLD] attention output
+  float *pend_h = pend_o + PT_SLOTS * VLD;                               // [PT_SLOTS][VLD] LN1(x1)
   float *hidb = pend_h + PT_SLOTS * VLD;                                 // [PT_SLOTS][I + 4] MLP hidden
 
   // ---- weights that stay on chip for the whole queue ----
@@ -122,15 +112,18 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
     const int k = e / E, f = e - k * E;
     waF[fidx<P>(f, k, nks_a)] = k < A ? W.action_wT[(size_t)k * E + f] : 0.f;
   }
-  for (int e = tid; e < E * E; e += 64 * PT_WAVES) wqT[e] = W.q_wT[e], woT[e] = W.attn_out_wT[e];
-  // K | V projection (rows 64..191 of attention.in_linear.weight [192][64]) as B fragments:
-  // n-tile nt < 4 -> key features 16 nt.., nt >= 4 -> value features; 4 k-steps of 16
-  uint4 wkv[8][4];
+  // K | V projection (rows 64..191 of attention.in_linear.weight [192][64]) as B fragments, 4
+  // k-steps of 16: the key rows (n-tile nt -> key features 16 nt..) live in 64 VGPRs for the whole
+  // kernel, the value rows in LDS, one 16-byte fragment per (n-tile, k-step, lane)
+  uint4 wk[4][4];
 #pragma unroll
-  for (int nt = 0; nt < 8; ++nt)
+  for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-      wkv[nt][ks] = ldg16(W.qkv_w + (size_t)(E + 16 * nt + r) * E + 16 * ks + 4 * q);
+      wk[nt][ks] = ldg16(W.qkv_w + (size_t)(E + 16 * nt + r) * E + 16 * ks + 4 * q);
+  for (int f = wave; f < 16; f += PT_WAVES)  // f = 4 nt + ks
+    *reinterpret_cast<uint4 *>(wvF + (f * 64 + lane) * 4) =
+        ldg16(W.qkv_w + (size_t)(2 * E + 16 * (f >> 2) + r) * E + 16 * (f & 3) + 4 * q);
   float bkv[8];
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) bkv[nt] = W.qkv_b[E + 16 * nt + r];
@@ -141,23 +134,61 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
     fvec[4 * E + tid] = W.ln0_w[tid], fvec[5 * E + tid] = W.ln0_b[tid];
   }
   // one value per lane (feature = lane) for the last-token phase
-  const float l1w = W.ln1_w[lane], l1b = W.ln1_b[lane];
   const float lfw = W.lnf_w[lane], lfb = W.lnf_b[lane];
-  const float bq = W.qkv_b[lane];
-  const float bo = W.attn_out_b[lane];
   const float pw = W.pref_w_last[lane];
   const float eps = W.eps;
   const float inv_sqrt_hd = 1.0f / sqrtf((float)HD);
   __syncthreads();
 
-  // ---- GPT2MLP + residual + final LayerNorm + value head of the parked tokens (slots < n) ----
-  // hidden = relu(h1 . Win^T + b): [16 x 64] . [64 x I], slots are the M rows (rows >= PT_SLOTS
-  // alias rows 0..7: their results are dropped); the wave's n-tiles are I / 16 / PT_WAVES apart.
-  // x2 = x1 + hidden . Wout^T + b: [16 x I] . [I x 64], one 16-feature n-tile per wave 0..3.
-  // B fragments come straight from the torch-layout weights ([out][in]: 16 B per lane).
+  // ---- everything behind the attention of the parked tokens (slots < n) ----
+  // Slots are the M rows of 16-row MFMA tiles (rows >= PT_SLOTS alias rows 0..7: their results are
+  // dropped).  B fragments come straight from the torch-layout weights ([out][in]: 16 B per lane).
+  //   x1 = x + o . Wo^T + b, h1 = LN1(x1)            [16 x 64] . [64 x 64], wave 0, LN in the C layout
+  //   hidden = relu(h1 . Win^T + b)                  [16 x 64] . [64 x I], n-tiles over the waves
+  //   x2 = x1 + hidden . Wout^T + b                  [16 x I] . [I x 64], one n-tile per wave 0..3
+  //   out = value head(LNf(x2))                      one slot per wave
   const int ldh = I + 4;
-  auto mlp_batch = [&](int n, int64_t first) {
-    __syncthreads();  // pend_x / pend_h of every slot written
+  auto tail_batch = [&](int n, int64_t first) {
+    __syncthreads();  // pend_x / pend_o of every slot written
+    if (wave == 0) {
+      f32x4 oa[4], x1[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        oa[ks] = *reinterpret_cast<const f32x4 *>(pend_o + (r & (PT_SLOTS - 1)) * VLD + 16 * ks + 4 * q);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float bias = W.attn_out_b[16 * nt + r];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x1[nt][i] = bias + pend_x[((4 * q + i) & (PT_SLOTS - 1)) * E + 16 * nt + r];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        uint4 bw[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bw[nt] = ldg16(W.attn_out_w + (size_t)(16 * nt + r) * E + 16 * ks + 4 * q);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            x1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[ks][c], __builtin_bit_cast(float4, bw[nt])[c], x1[nt], 0, 0, 0);
+      }
+      float lw[4], lb[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) lw[nt] = W.ln1_w[16 * nt + r], lb[nt] = W.ln1_b[16 * nt + r];
+      f32x4 h1[4] = {x1[0], x1[1], x1[2], x1[3]};
+      layer_norm_tile(h1, lw, lb, eps);
+      asm volatile("" ::: "memory");  // pend_x was read above by this wave: keep the order
+      if (q < PT_SLOTS / 4) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            pend_x[(4 * q + i) * E + 16 * nt + r] = x1[nt][i];
+            pend_h[(4 * q + i) * VLD + 16 * nt + r] = h1[nt][i];
+          }
+      }
+    }
+    __syncthreads();
     {
       f32x4 ha[4];
 #pragma unroll
@@ -236,7 +267,11 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
     const int T = 2 * len;
     const int nmt = (len + 15) >> 4;  // 16-token tiles per kind
     // ================= every token: embedding, LayerNorms, key / value =================
-    for (int job = wave; job < 2 * nmt; job += PT_WAVES) {
+    // The job of the last action tile also projects the queries: it trades places with the job
+    // of the last wave's first round (a wave with one job when there are <= 2 PT_WAVES - 2 jobs).
+    const int njobs = 2 * nmt, qjob = njobs - 1, qslot = qjob < PT_WAVES - 1 ? qjob : PT_WAVES - 1;
+    for (int jslot = wave; jslot < njobs; jslot += PT_WAVES) {
+      const int job = jslot == qslot ? qjob : (jslot == qjob ? qslot : jslot);
       const int kind = job >= nmt ? 1 : 0;  // 0: state tokens, 1: action tokens
       const int mt = kind ? job - nmt : job;
       const float *src = kind ? act : obs;
@@ -298,13 +333,13 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) lw[nt] = fvec[4 * E + 16 * nt + r], lb[nt] = fvec[5 * E + 16 * nt + r];
       if (!(skip & 2)) layer_norm_tile(h, lw, lb, eps);  // block pre-LN
-      // the window's last token (action token len - 1) feeds the query / residual path
-      if (kind == 1 && mt == nmt - 1) {
+      // the window's last token (action token len - 1): its residual stream is parked for tail_batch
+      if (job == qjob) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (16 * mt + 4 * q + i == len - 1) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) xlast[16 * nt + r] = x[nt][i], hlast[16 * nt + r] = h[nt][i];
+            for (int nt = 0; nt < 4; ++nt) pend_x[nslot * E + 16 * nt + r] = x[nt][i];
           }
         }
       }
@@ -323,6 +358,35 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
       for (int ks = 0; ks < 4; ++ks)
         ha[ks] = *reinterpret_cast<const uint4 *>(scr + (size_t)rr * 2 * VLD + 16 * ks + 4 * q);
       asm volatile("" ::: "memory");  // the V rows written below are the scratch read above
+      if (job == qjob) {
+        // queries of the tile (rows 0..63 of attention.in_linear), B fragments from global / L2;
+        // only the last token's row is kept, rounded to bf16 (ops.py:74)
+        f32x4 qa[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const float bias = W.qkv_b[16 * nt + r];
+          qa[nt] = f32x4{bias, bias, bias, bias};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          uint4 bw[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) bw[nt] = ldg16(W.qkv_w + (size_t)(16 * nt + r) * E + 16 * ks + 4 * q);
+          const float4 af = __builtin_bit_cast(float4, ha[ks]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+              qa[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], __builtin_bit_cast(float4, bw[nt])[c], qa[nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (16 * mt + 4 * q + i == len - 1) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) qlast[16 * nt + r] = rbf(qa[nt][i]);
+          }
+        }
+      }
       f32x4 kv[8];
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) kv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -331,12 +395,18 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
 #pragma unroll
       for (int ks = 0; ks < ((skip & 16) ? 0 : 4); ++ks) {
         const float4 af = __builtin_bit_cast(float4, ha[ks]);
+        float4 bv[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const float4 *>(wvF + ((4 * nt + ks) * 64 + lane) * 4);
 #pragma unroll
-          for (int nt = 0; nt < 8; ++nt)
-            kv[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], __builtin_bit_cast(float4, wkv[nt][ks])[c], kv[nt],
-                                                          0, 0, 0);
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            kv[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], __builtin_bit_cast(float4, wk[nt][ks])[c], kv[nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            kv[4 + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], bv[nt][c], kv[4 + nt], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -357,12 +427,10 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
       if (tid == 0) out[win] = 0.f;
       continue;
     }
-    float qv = bq;
-#pragma unroll 8
-    for (int j = 0; j < E; ++j) qv += hlast[j] * wqT[j * E + lane];
-    const float qb = rbf(qv);  // ops.py:74
+    const float qb = qlast[lane];
     const int head = lane / HD;
     float lmax = -3.0e38f;
+#pragma unroll 2
     for (int t = wave; t < T; t += PT_WAVES) {
       float s = seg_sum(qb * bf2f(Kb[(size_t)t * E + lane]), HD);
       s = rbf(rbf(s) * inv_sqrt_hd);  // bf16 product tensor, bf16 scale (ops.py:76-79)
@@ -375,6 +443,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
 #pragma unroll
     for (int w = 1; w < PT_WAVES; ++w) gmax = fmaxf(gmax, stat[w * 16 + head]);
     float lsum = 0.f, oacc = 0.f;
+#pragma unroll 2
     for (int t = wave; t < T; t += PT_WAVES) {
       const float p = expf(lg[t * NH + head] - gmax);
       lsum += p;
@@ -383,27 +452,19 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
     part[wave * E + lane] = oacc;
     if ((lane % HD) == 0) stat[PT_WAVES * 16 + wave * 16 + head] = lsum;
     __syncthreads();
-    {
+    // Every LDS word the next window's token phase writes (keys, values, the query) has been read
+    // by now; what is read below (part, stat) is next written behind two more barriers.
+    if (wave == 0) {  // park the attention output: the rest of the block runs in tail_batch
       float o = 0.f, den = 0.f;
 #pragma unroll
       for (int w = 0; w < PT_WAVES; ++w) o += part[w * E + lane], den += stat[PT_WAVES * 16 + w * 16 + head];
-      if (wave == 0) ovec[lane] = o / den;
+      pend_o[nslot * VLD + lane] = o / den;
     }
-    __syncthreads();
-    // ---- out projection + residual, LN1 (all waves redundantly: 64 FMAs) ----
-    float x1 = bo + xlast[lane];
-#pragma unroll 8
-    for (int j = 0; j < E; ++j) x1 += ovec[j] * woT[j * E + lane];
-    const float h1 = layer_norm(x1, l1w, l1b, eps);
-    // park the token: its MLP runs with the other slots' (mlp_batch below)
-    if (wave == 0) pend_x[nslot * E + lane] = x1, pend_h[nslot * VLD + lane] = h1;
     if (nslot == 0) batch_first = win;
     ++nslot;
     if (nslot == PT_SLOTS || win + (int64_t)gridDim.x >= n_win) {
-      mlp_batch(nslot, batch_first);
+      tail_batch(nslot, batch_first);
       nslot = 0;
-    } else {
-      __syncthreads();  // LDS is reused by the next window
     }
   }
 }
@@ -411,9 +472,9 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
 size_t pt_smem_bytes(const iqlhip_pt_weights &W, int ql) {
   const size_t Tmax = 2 * (size_t)ql;
   const size_t ks = (size_t)round_up(W.state_dim, 16) + round_up(W.action_dim, 16);
-  return Tmax * VLD * 4 + Tmax * E * 2 + ks * E * 4 + 2 * E * E * 4 +
-         (3 * E + PT_WAVES * E + 2 * PT_WAVES * 16 + round_up((int)Tmax * W.num_heads, 4) + 6 * E + PT_SLOTS * E +
-          PT_SLOTS * VLD + PT_SLOTS * (W.inter_dim + 4)) * 4 + 64;
+  return Tmax * VLD * 4 + Tmax * E * 2 + ks * E * 4 + 4 * 4 * 64 * 16 +
+         (E + PT_WAVES * E + 2 * PT_WAVES * 16 + round_up((int)Tmax * W.num_heads, 4) + 6 * E + PT_SLOTS * E +
+          2 * PT_SLOTS * VLD + PT_SLOTS * (W.inter_dim + 4)) * 4 + 64;
 }
 
 hipError_t launch_pt(const iqlhip_pt_weights &W, const float *obs, const float *act, int64_t n_rows,

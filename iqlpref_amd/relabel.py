@@ -556,8 +556,7 @@ class RewardPT(nn.Module):
             sln_w=f(self.stacked_layer_norm.weight), sln_b=f(self.stacked_layer_norm.bias),
             ln0_w=f(blk.layer_norm_0.weight), ln0_b=f(blk.layer_norm_0.bias),
             qkv_w=f(blk.attention.in_linear.weight), qkv_b=f(blk.attention.in_linear.bias),
-            q_wT=f(blk.attention.in_linear.weight[:self.state_linear.out_features].t()),
-            attn_out_wT=f(blk.attention.out_linear.weight.t()), attn_out_b=f(blk.attention.out_linear.bias),
+            attn_out_w=f(blk.attention.out_linear.weight), attn_out_b=f(blk.attention.out_linear.bias),
             ln1_w=f(blk.layer_norm_1.weight), ln1_b=f(blk.layer_norm_1.bias),
             mlp_in_w=f(blk.mlp.in_linear.weight), mlp_in_b=f(blk.mlp.in_linear.bias),
             mlp_out_w=f(blk.mlp.out_linear.weight), mlp_out_b=f(blk.mlp.out_linear.bias),
