@@ -34,12 +34,19 @@ namespace iqlhip {
 
 constexpr int E = 64;
 constexpr int PT_WAVES = 8;
-constexpr int VLD = E + 4;  // row stride of the V rows (floats): conflict-free A-fragment reads
+constexpr int VLD = E + 4;  // row stride of the V rows (floats): conflict-free A-fragment reads; column 64 holds 1
+constexpr int KLD = E + 8;  // row stride of the bf16 K rows (144 B): conflict-free 16-byte B-fragment reads
 constexpr int PT_SLOTS = 8; // windows whose last-token MLP is batched (= PT_WAVES: one final LayerNorm per wave)
 
 __device__ __forceinline__ float wave_sum(float v) { return lane_sum<64>(v); }
 __device__ __forceinline__ float seg_sum(float v, int width) { return lane_sum_rt(v, width); }  // pow2 groups
 __device__ __forceinline__ float sum16(float v) { return lane_sum<16>(v); }  // the 16 lanes sharing lane >> 4
+__device__ __forceinline__ float max16(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  return fmaxf(v, dpp_mov<0x140>(v));
+}
 // LayerNorm over the 64 lanes (flax/torch: biased variance, eps inside the sqrt)
 __device__ __forceinline__ float layer_norm(float x, float w, float b, float eps) {
   const float mu = wave_sum(x) * (1.0f / E);
@@ -57,9 +64,9 @@ __device__ __forceinline__ void layer_norm_tile(f32x4 (&x)[4], const float (&w)[
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) d[nt] = x[nt][i] - mu;
     const float var = sum16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / E);
-    const float rs = sqrtf(var + eps);
+    const float inv = 1.0f / sqrtf(var + eps);  // (flax multiplies by rsqrt as well)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) x[nt][i] = d[nt] / rs * w[nt] + b[nt];
+    for (int nt = 0; nt < 4; ++nt) x[nt][i] = d[nt] * inv * w[nt] + b[nt];
   }
 }
 
@@ -84,12 +91,13 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
   const int r = lane & 15, q = lane >> 4;
   const int S = W.state_dim, A = W.action_dim, I = W.inter_dim, NH = W.num_heads;
   const int HD = E / NH;
+  const int hds = __builtin_ctz(HD);  // HD is a power of two
   const int Tmax = 2 * ql;
   const int nks_s = round_up(S, 16) / 16, nks_a = round_up(A, 16) / 16;
   // ---- LDS carve ----
   float *Vs = reinterpret_cast<float *>(smem);                          // [Tmax][VLD]
-  uint16_t *Kb = reinterpret_cast<uint16_t *>(Vs + (size_t)Tmax * VLD);  // [Tmax][64] bf16
-  float *wsF = reinterpret_cast<float *>(Kb + (size_t)Tmax * E);         // fragment-major [64][16 nks_s]
+  uint16_t *Kb = reinterpret_cast<uint16_t *>(Vs + (size_t)Tmax * VLD);  // [Tmax][KLD] bf16
+  float *wsF = reinterpret_cast<float *>(Kb + (size_t)Tmax * KLD);         // fragment-major [64][16 nks_s]
   float *waF = wsF + nks_s * 16 * E;                                     // fragment-major [64][16 nks_a]
   float *wvF = waF + nks_a * 16 * E;                                     // [4 nt][4 ks][64 lanes][4] value projection
   float *qlast = wvF + 4 * 4 * 64 * 4;                                   // [64] last token's query (bf16 values)
@@ -127,6 +135,10 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
   float bkv[8];
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) bkv[nt] = W.qkv_b[E + 16 * nt + r];
+  // V rows start finite (rows past a window's length are multiplied by zero weights), column 64 = 1
+  // (the softmax denominator falls out of the P.V product), columns 65..67 = 0: never written again
+  for (int e = tid; e < Tmax * VLD; e += 64 * PT_WAVES) Vs[e] = (e % VLD) == E ? 1.f : 0.f;
+  for (int e = tid; e < Tmax * KLD / 2; e += 64 * PT_WAVES) reinterpret_cast<uint32_t *>(Kb)[e] = 0u;
   // per-feature vectors of the token jobs (read from LDS in the C layout: feature 16 nt + r)
   if (tid < E) {
     fvec[tid] = W.state_b[tid], fvec[E + tid] = W.action_b[tid];
@@ -415,7 +427,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
           const int t = 2 * k + kind;
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
-            Kb[(size_t)t * E + 16 * nt + r] = f2bf(kv[nt][i] + bkv[nt]);
+            Kb[(size_t)t * KLD + 16 * nt + r] = f2bf(kv[nt][i] + bkv[nt]);
             Vs[(size_t)t * VLD + 16 * nt + r] = kv[4 + nt][i] + bkv[4 + nt];
           }
         }
@@ -427,30 +439,87 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
       if (tid == 0) out[win] = 0.f;
       continue;
     }
-    const float qb = qlast[lane];
-    const int head = lane / HD;
-    float lmax = -3.0e38f;
-#pragma unroll 2
-    for (int t = wave; t < T; t += PT_WAVES) {
-      float s = seg_sum(qb * bf2f(Kb[(size_t)t * E + lane]), HD);
-      s = rbf(rbf(s) * inv_sqrt_hd);  // bf16 product tensor, bf16 scale (ops.py:76-79)
-      if ((lane % HD) == 0) lg[t * NH + head] = s;
-      lmax = fmaxf(lmax, s);
-    }
-    if ((lane % HD) == 0) stat[wave * 16 + head] = lmax;
-    __syncthreads();
-    float gmax = stat[head];
+    // ---- logits of the one query over all keys: [16 heads x 64] . [64 x T] on the bf16 matrix
+    // cores.  Row m of the A operand is the query masked to head m's features, so C[m][t] is head
+    // m's bf16 q.k product (exact products, fp32 accumulation, rounded to bf16 as ops.py:76) ----
+    {
+      uint4 qa[2];
 #pragma unroll
-    for (int w = 1; w < PT_WAVES; ++w) gmax = fmaxf(gmax, stat[w * 16 + head]);
-    float lsum = 0.f, oacc = 0.f;
-#pragma unroll 2
-    for (int t = wave; t < T; t += PT_WAVES) {
-      const float p = expf(lg[t * NH + head] - gmax);
-      lsum += p;
-      oacc += p * Vs[(size_t)t * VLD + lane];
+      for (int ks = 0; ks < 2; ++ks) {
+        const int f0 = 32 * ks + 8 * q;
+        const float4 v0 = *reinterpret_cast<const float4 *>(qlast + f0);
+        const float4 v1 = *reinterpret_cast<const float4 *>(qlast + f0 + 4);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t lo = ((f0 + 2 * e) >> hds) == r ? f2bf(v[2 * e]) : 0u;
+          const uint32_t hi = ((f0 + 2 * e + 1) >> hds) == r ? f2bf(v[2 * e + 1]) : 0u;
+          w[e] = lo | (hi << 16);
+        }
+        qa[ks] = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      float lmax[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+      for (int j = wave; 16 * j < T; j += PT_WAVES) {
+        const int t = 16 * j + r;
+        const uint16_t *krow = Kb + (size_t)(t < T ? t : T - 1) * KLD + 8 * q;
+        const uint4 k0 = *reinterpret_cast<const uint4 *>(krow), k1 = *reinterpret_cast<const uint4 *>(krow + 32);
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        Prec<true>::mma(qa[0], k0, c);
+        Prec<true>::mma(qa[1], k1, c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (4 * q + i < NH && t < T) {
+            const float sc = rbf(rbf(c[i]) * inv_sqrt_hd);  // bf16 product tensor, bf16 scale (ops.py:76-79)
+            lg[t * NH + 4 * q + i] = sc;
+            lmax[i] = fmaxf(lmax[i], sc);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float m = max16(lmax[i]);
+        if (r == 0 && 4 * q + i < NH) stat[wave * 16 + 4 * q + i] = m;
+      }
     }
-    part[wave * E + lane] = oacc;
-    if ((lane % HD) == 0) stat[PT_WAVES * 16 + wave * 16 + head] = lsum;
+    __syncthreads();
+    // ---- softmax numerators and P.V: [16 heads x T] . [T x 64 (+ the ones column)] on the exact
+    // fp32 matrix cores, the keys split over the waves; C[m][f] is wanted for m = head of f ----
+    const int head = lane >> hds;
+    {
+      float gmax = -3.0e38f;
+      if (r < NH) {
+#pragma unroll
+        for (int w = 0; w < PT_WAVES; ++w) gmax = fmaxf(gmax, stat[w * 16 + r]);
+      }
+      f32x4 oc[5];
+#pragma unroll
+      for (int nt = 0; nt < 5; ++nt) oc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ks = wave; 4 * ks < T; ks += PT_WAVES) {
+        const int t = 4 * ks + q;
+        float a = 0.f;
+        if (r < NH && t < T) a = expf(lg[t * NH + r] - gmax);
+        const float *vrow = Vs + (size_t)(t < T ? t : T - 1) * VLD + r;
+        float bv[5];
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) bv[nt] = vrow[16 * nt];
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) oc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[nt], oc[nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int h = (16 * nt + r) >> hds;
+        if ((h >> 2) == q) {
+          const int i = h & 3;
+          part[wave * E + 16 * nt + r] = i == 0 ? oc[nt][0] : i == 1 ? oc[nt][1] : i == 2 ? oc[nt][2] : oc[nt][3];
+        }
+      }
+      if (r == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 * q + i < NH) stat[PT_WAVES * 16 + wave * 16 + 4 * q + i] = oc[4][i];
+      }
+    }
     __syncthreads();
     // Every LDS word the next window's token phase writes (keys, values, the query) has been read
     // by now; what is read below (part, stat) is next written behind two more barriers.
@@ -472,7 +541,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
 size_t pt_smem_bytes(const iqlhip_pt_weights &W, int ql) {
   const size_t Tmax = 2 * (size_t)ql;
   const size_t ks = (size_t)round_up(W.state_dim, 16) + round_up(W.action_dim, 16);
-  return Tmax * VLD * 4 + Tmax * E * 2 + ks * E * 4 + 4 * 4 * 64 * 16 +
+  return Tmax * VLD * 4 + Tmax * KLD * 2 + ks * E * 4 + 4 * 4 * 64 * 16 +
          (E + PT_WAVES * E + 2 * PT_WAVES * 16 + round_up((int)Tmax * W.num_heads, 4) + 6 * E + PT_SLOTS * E +
           2 * PT_SLOTS * VLD + PT_SLOTS * (W.inter_dim + 4)) * 4 + 64;
 }
