@@ -400,6 +400,15 @@ def agents_leg(ia, torch, tr, buf, device, seed, args, unroll, bytes_step):
         torch.cuda.synchronize()
         scan[str(k_)] = k_ * 5_000 / (time.perf_counter() - t1)
         g_.close()
+        if k_ == 4:  # two sub-groups of two on two streams: launches that do not fill the chip overlap
+            g_ = ia.SeedGroup(trs[:k_], mode="split", n_streams=2)
+            g_.train_steps(buf, 1_000, BATCH, graph_unroll=u)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            g_.train_steps(buf, 5_000, BATCH, graph_unroll=u)
+            torch.cuda.synchronize()
+            scan["4 (2 streams x 2)"] = k_ * 5_000 / (time.perf_counter() - t1)
+            g_.close()
     group = ia.SeedGroup(trs)
     group.train_steps(buf, 2_000, BATCH, graph_unroll=u)
     torch.cuda.synchronize()

@@ -12,6 +12,12 @@ is bit-identical to running it alone.  Two execution modes:
     boundaries per seed-step.
 ``mode="streams"``
     every trainer replays its own hipGraph on its own HIP stream; the launches interleave.
+``mode="split"`` (``n_streams=G``)
+    G sub-groups, each stepped by its own launch sequence on its own HIP stream.  While a launch
+    does not fill the chip (K <= 2 seeds per launch: at most two work-groups per CU) the kernels
+    of two sub-groups run side by side -- one's HBM-bound k_update beside the other's
+    latency-bound k_forward: four seeds as 2 x 2 measured 142k steps/s against 119k as one group
+    of four (tools/group_streams.py); larger sub-groups fill the chip and gain nothing.
 """
 import ctypes as C
 from typing import List, Optional, Sequence, Union
@@ -29,7 +35,8 @@ def _shape_key(t: ImplicitQLearning):
 
 
 class SeedGroup:
-    def __init__(self, trainers: Sequence[ImplicitQLearning], chunk: int = 2000, mode: Optional[str] = None):
+    def __init__(self, trainers: Sequence[ImplicitQLearning], chunk: int = 2000, mode: Optional[str] = None,
+                 n_streams: int = 2):
         if not trainers:
             raise ValueError("SeedGroup needs at least one trainer")
         devs = {t._dev for t in trainers}
@@ -40,9 +47,9 @@ class SeedGroup:
         one_shape = len({_shape_key(t) for t in trainers}) == 1 and len(trainers) <= _lib.MAX_GROUP
         if mode is None:
             mode = "group" if one_shape else "streams"
-        if mode not in ("group", "streams"):
-            raise ValueError("mode must be 'group' or 'streams'")
-        if mode == "group" and not one_shape:
+        if mode not in ("group", "streams", "split"):
+            raise ValueError("mode must be 'group', 'streams' or 'split'")
+        if mode in ("group", "split") and not one_shape:
             raise ValueError(f"mode='group' needs at most {_lib.MAX_GROUP} trainers of one shape (dims, hidden, "
                              "precision, policy kind, critics, dropout on/off)")
         self.mode = mode
@@ -53,6 +60,18 @@ class SeedGroup:
         self._chunk = int(chunk)
         self._group = None
         self._group_batch = None
+        self._children: List["SeedGroup"] = []
+        self._child_slices: List[slice] = []
+        if mode == "split":
+            G = max(1, min(int(n_streams), len(self.trainers)))
+            base, extra, lo = len(self.trainers) // G, len(self.trainers) % G, 0
+            for g in range(G):  # contiguous runs of trainers, sizes differing by at most one
+                hi = lo + base + (1 if g < extra else 0)
+                self._children.append(SeedGroup(self.trainers[lo:hi], mode="group"))
+                self._child_slices.append(slice(lo, hi))
+                lo = hi
+            self._streams = [torch.cuda.Stream(device=self._dev) for _ in self._children]
+            self._chunk = min(self._chunk, 500)  # short turns keep the queues of all streams fed
 
     def __len__(self):
         return len(self.trainers)
@@ -82,6 +101,8 @@ class SeedGroup:
 
     def close(self):
         """Dissolve the device-side group; the trainers stay usable on their own."""
+        for ch in getattr(self, "_children", []):
+            ch.close()
         self._drop_group()
 
     def __del__(self):
@@ -111,6 +132,8 @@ class SeedGroup:
             raise ValueError("indices / dropout_keep: one entry per trainer")
         if self.mode == "streams":
             return self._train_streams(bufs, n_steps, batch_size, idx, keep, return_losses, graph_unroll)
+        if self.mode == "split":
+            return self._train_split(bufs, n_steps, batch_size, idx, keep, return_losses, graph_unroll)
         self._ensure_group(batch_size)
         for i, t in enumerate(idx):
             if t is not None:
@@ -151,6 +174,29 @@ class SeedGroup:
                                        graph_unroll=graph_unroll)
                     if return_losses:
                         out[k].append(r)
+            done += c
+        for st in self._streams:
+            cur.wait_stream(st)
+        if return_losses:
+            return [torch.cat(o) for o in out]
+        return None
+
+    def _train_split(self, bufs, n_steps, batch_size, idx, keep, return_losses, graph_unroll):
+        cur = torch.cuda.current_stream(self._dev)
+        for st in self._streams:
+            st.wait_stream(cur)
+        out = [[] for _ in self.trainers]
+        done = 0
+        while done < n_steps:
+            c = min(self._chunk, n_steps - done)
+            for ch, sl, st in zip(self._children, self._child_slices, self._streams):
+                cut = lambda ts: [None if t is None else t[done:done + c] for t in ts[sl]]
+                with torch.cuda.stream(st):
+                    r = ch.train_steps(bufs[sl], c, batch_size, indices=cut(idx), dropout_keep=cut(keep),
+                                       return_losses=return_losses, graph_unroll=graph_unroll)
+                if return_losses:
+                    for k, rk in zip(range(sl.start, sl.stop), r):
+                        out[k].append(rk)
             done += c
         for st in self._streams:
             cur.wait_stream(st)

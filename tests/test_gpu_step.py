@@ -382,10 +382,10 @@ def test_shapes_beyond_the_goldens_vs_oracle(gh, S, A, H, B, det, drop, E, mode)
                 assert (diff > 2e-6).mean() < 1e-4, f"{name}/{k}: {(diff > 2e-6).mean():.2e} of elements off"
 
 
-@pytest.mark.parametrize("mode", ["group", "streams"])
+@pytest.mark.parametrize("mode", ["group", "streams", "split"])
 def test_seed_group_matches_separate_runs(gh, mode):
-    """Several seeds on one GPU -- one launch sequence with gridDim.y = K ("group") or one stream
-    per seed ("streams"), shared buffer -- = the same seeds run alone, bit for bit: losses of every
+    """Several seeds on one GPU -- one launch sequence with gridDim.y = K ("group"), one stream
+    per seed ("streams") or two sub-groups on two streams ("split"), shared buffer -- = the same seeds run alone, bit for bit: losses of every
     step, every parameter, Adam moment and target weight."""
     import iqlpref_amd as ia
     d, hyper, data, nets = helpers.load_traj("traj_antmaze", "bf16")
