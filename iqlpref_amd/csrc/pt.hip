@@ -109,7 +109,6 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
   float *pend_o = pend_x + PT_SLOTS * E;                                 // [PT_SLOTS][VLD] attention output
   float *pend_h = pend_o + PT_SLOTS * VLD;                               // [PT_SLOTS][VLD] LN1(x1)
   float *hidb = pend_h + PT_SLOTS * VLD;                                 // [PT_SLOTS][I + 4] MLP hidden
-  int *hflag = reinterpret_cast<int *>(hidb + PT_SLOTS * (I + 4));       // [2 ql / 16 + 2] hand-over flags, one per job slot
 
   // ---- weights that stay on chip for the whole queue ----
   // embedding weights as MFMA B fragments (common.h fidx): element (feature f, input k), zero padded
@@ -140,7 +139,6 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
   // (the softmax denominator falls out of the P.V product), columns 65..67 = 0: never written again
   for (int e = tid; e < Tmax * VLD; e += 64 * PT_WAVES) Vs[e] = (e % VLD) == E ? 1.f : 0.f;
   for (int e = tid; e < Tmax * KLD / 2; e += 64 * PT_WAVES) reinterpret_cast<uint32_t *>(Kb)[e] = 0u;
-  for (int e = tid; e < 2 * ((ql + 15) / 16); e += 64 * PT_WAVES) hflag[e] = 0;
   // per-feature vectors of the token jobs (read from LDS in the C layout: feature 16 nt + r)
   if (tid < E) {
     fvec[tid] = W.state_b[tid], fvec[E + tid] = W.action_b[tid];
@@ -273,7 +271,6 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
   };
   int nslot = 0;
   int64_t batch_first = 0;
-  int seq = 0;  // window counter of this work-group: the value a hand-over flag takes
 
   for (int64_t win = blockIdx.x; win < n_win; win += gridDim.x) {
     const int64_t start = win_start[win];
@@ -282,173 +279,156 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
     const int T = 2 * len;
     const int nmt = (len + 15) >> 4;  // 16-token tiles per kind
     // ================= every token: embedding, LayerNorms, key / value =================
-    // Waves w and w + 4 share a SIMD.  Waves 0..3 ("front") run the VALU-heavy half of a job
-    // (gather, embedding GEMM, both LayerNorms) and hand the normalised tile over in LDS; waves
-    // 4..7 ("back") run the MFMA-heavy half (K | V projection, the query projection of the last
-    // tile, K / V stores).  The vector and the matrix pipes of every SIMD are then busy at the
-    // same time; with both halves in every wave the partner waves moved through them in lockstep
-    // and the phases added up (tools/pt_diag.py).
-    // Pair p takes the job slots p, p + 4, ...; pair 3 has the fewest, so the job of the last
-    // action tile (which also projects the queries) trades places with slot 3.
-    ++seq;
-    const int njobs = 2 * nmt, qjob = njobs - 1, qslot = njobs > 3 ? 3 : qjob;
-    const int pair = wave & 3;
-    for (int jslot = pair; jslot < njobs; jslot += 4) {
+    // The job of the last action tile also projects the queries: it trades places with the job
+    // of the last wave's first round (a wave with one job when there are <= 2 PT_WAVES - 2 jobs).
+    const int njobs = 2 * nmt, qjob = njobs - 1, qslot = qjob < PT_WAVES - 1 ? qjob : PT_WAVES - 1;
+    for (int jslot = wave; jslot < njobs; jslot += PT_WAVES) {
       const int job = jslot == qslot ? qjob : (jslot == qjob ? qslot : jslot);
       const int kind = job >= nmt ? 1 : 0;  // 0: state tokens, 1: action tokens
       const int mt = kind ? job - nmt : job;
-      // the tile's rows of V double as the hand-over buffer (token j of the tile -> row 2 (16 mt + j) + kind)
-      float *scr = Vs + (size_t)(2 * 16 * mt + kind) * VLD;
-      if (wave < 4) {
-        // ---------------- front ----------------
-        const float *src = kind ? act : obs;
-        const int D = kind ? A : S, nks = kind ? nks_a : nks_s;
-        const float *wF = kind ? waF : wsF;
-        // A fragments from the dataset rows: token 16 mt + r of the window (clamped past len: the
-        // results of those rows are dropped), inputs 16 ks + 4 q .. + 3 (clamped past D: zeroed)
-        const int kr = 16 * mt + r < len ? 16 * mt + r : len - 1;
-        const float *rowp = src + (size_t)(start + kr) * D;
-        // accumulators start from bias + timestep embedding of tokens 4 q + i (timestep = t0 +
-        // position in the window; t0 = 0 in ref:1281,1291, the true step in custom_offline:209)
-        f32x4 x[4];
+      const float *src = kind ? act : obs;
+      const int D = kind ? A : S, nks = kind ? nks_a : nks_s;
+      const float *wF = kind ? waF : wsF;
+      // A fragments from the dataset rows: token 16 mt + r of the window (clamped past len: the
+      // results of those rows are dropped), inputs 16 ks + 4 q .. + 3 (clamped past D: zeroed)
+      const int kr = 16 * mt + r < len ? 16 * mt + r : len - 1;
+      const float *rowp = src + (size_t)(start + kr) * D;
+      // accumulators start from bias + timestep embedding of tokens 4 q + i (timestep = t0 +
+      // position in the window; t0 = 0 in ref:1281,1291, the true step in custom_offline:209)
+      f32x4 x[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int k = 16 * mt + 4 * q + i < len ? 16 * mt + 4 * q + i : len - 1;
+      for (int i = 0; i < 4; ++i) {
+        const int k = 16 * mt + 4 * q + i < len ? 16 * mt + 4 * q + i : len - 1;
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            x[nt][i] = (skip & 4) ? 0.5f : ldg(W.temb + (size_t)(t0 + k) * E + 16 * nt + r);
+        for (int nt = 0; nt < 4; ++nt) x[nt][i] = (skip & 4) ? 0.5f : ldg(W.temb + (size_t)(t0 + k) * E + 16 * nt + r);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float bias = fvec[kind * E + 16 * nt + r];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[nt][i] += bias;
+      }
+      for (int ks0 = 0; ks0 < nks; ks0 += KCH) {
+        uint4 a[KCH];
+#pragma unroll
+        for (int kk = 0; kk < KCH; ++kk) {
+          float v[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int k = 16 * (ks0 + kk) + 4 * q + c;
+            const float xv = (skip & 4) ? 0.25f : ldg(rowp + (k < D ? k : D - 1));
+            v[c] = k < D ? xv : 0.f;
+          }
+          a[kk] = __builtin_bit_cast(uint4, make_float4(v[0], v[1], v[2], v[3]));
         }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const float bias = fvec[kind * E + 16 * nt + r];
+        for (int kk = 0; kk < KCH; ++kk) {
+          if (ks0 + kk < nks) {
+            float4 bf[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) x[nt][i] += bias;
-        }
-        for (int ks0 = 0; ks0 < nks; ks0 += KCH) {
-          uint4 a[KCH];
-#pragma unroll
-          for (int kk = 0; kk < KCH; ++kk) {
-            float v[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const int k = 16 * (ks0 + kk) + 4 * q + c;
-              const float xv = (skip & 4) ? 0.25f : ldg(rowp + (k < D ? k : D - 1));
-              v[c] = k < D ? xv : 0.f;
-            }
-            a[kk] = __builtin_bit_cast(uint4, make_float4(v[0], v[1], v[2], v[3]));
-          }
-#pragma unroll
-          for (int kk = 0; kk < KCH; ++kk) {
-            if (ks0 + kk < nks) {
-              float4 bf[4];
-#pragma unroll
-              for (int nt = 0; nt < 4; ++nt)
-                bf[nt] = *reinterpret_cast<const float4 *>(wF + frag_off<P>(nt, ks0 + kk, nks, lane));
-              const float4 af = __builtin_bit_cast(float4, a[kk]);
-#pragma unroll
-              for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                  x[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], bf[nt][c], x[nt], 0, 0, 0);
-            }
-          }
-        }
-        float lw[4], lb[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) lw[nt] = fvec[2 * E + 16 * nt + r], lb[nt] = fvec[3 * E + 16 * nt + r];
-        if (!(skip & 2)) layer_norm_tile(x, lw, lb, eps);  // stacked_layer_norm
-        // the window's last token (action token len - 1): its residual stream is parked for tail_batch
-        if (job == qjob) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (16 * mt + 4 * q + i == len - 1) {
-#pragma unroll
-              for (int nt = 0; nt < 4; ++nt) pend_x[nslot * E + 16 * nt + r] = x[nt][i];
-            }
-          }
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) lw[nt] = fvec[4 * E + 16 * nt + r], lb[nt] = fvec[5 * E + 16 * nt + r];
-        if (!(skip & 2)) layer_norm_tile(x, lw, lb, eps);  // block pre-LN (x now holds h)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (16 * mt + 4 * q + i < ql) scr[(size_t)(4 * q + i) * 2 * VLD + 16 * nt + r] = x[nt][i];
-        // hand over: the tile first, then the flag (LDS serves one wave's requests in order)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&hflag[jslot], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else {
-        // ---------------- back ----------------
-        while (__hip_atomic_load(&hflag[jslot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
-          __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        uint4 ha[4];
-        const int rr = 16 * mt + r < ql ? r : 0;  // rows past the LDS image (never stored) re-read row 0
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          ha[ks] = *reinterpret_cast<const uint4 *>(scr + (size_t)rr * 2 * VLD + 16 * ks + 4 * q);
-        asm volatile("" ::: "memory");  // the V rows written below are the buffer read above
-        if (job == qjob) {
-          // queries of the tile (rows 0..63 of attention.in_linear), B fragments from global / L2;
-          // only the last token's row is kept, rounded to bf16 (ops.py:74)
-          f32x4 qa[4];
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const float bias = W.qkv_b[16 * nt + r];
-            qa[nt] = f32x4{bias, bias, bias, bias};
-          }
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            uint4 bw[4];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bw[nt] = ldg16(W.qkv_w + (size_t)(16 * nt + r) * E + 16 * ks + 4 * q);
-            const float4 af = __builtin_bit_cast(float4, ha[ks]);
+            for (int nt = 0; nt < 4; ++nt)
+              bf[nt] = *reinterpret_cast<const float4 *>(wF + frag_off<P>(nt, ks0 + kk, nks, lane));
+            const float4 af = __builtin_bit_cast(float4, a[kk]);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
               for (int nt = 0; nt < 4; ++nt)
-                qa[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], __builtin_bit_cast(float4, bw[nt])[c], qa[nt], 0, 0, 0);
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (16 * mt + 4 * q + i == len - 1) {
-#pragma unroll
-              for (int nt = 0; nt < 4; ++nt) qlast[16 * nt + r] = rbf(qa[nt][i]);
-            }
+                x[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], bf[nt][c], x[nt], 0, 0, 0);
           }
         }
-        f32x4 kv[8];
+      }
+      float lw[4], lb[4];
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) kv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // component-major: the four K = 4 MFMAs of one fragment pair accumulate into the same
-        // registers; issuing the other seven n-tiles between them hides the dependent latency
+      for (int nt = 0; nt < 4; ++nt) lw[nt] = fvec[2 * E + 16 * nt + r], lb[nt] = fvec[3 * E + 16 * nt + r];
+      if (!(skip & 2)) layer_norm_tile(x, lw, lb, eps);  // stacked_layer_norm
+      f32x4 h[4] = {x[0], x[1], x[2], x[3]};
 #pragma unroll
-        for (int ks = 0; ks < ((skip & 16) ? 0 : 4); ++ks) {
-          const float4 af = __builtin_bit_cast(float4, ha[ks]);
-          float4 bv[4];
+      for (int nt = 0; nt < 4; ++nt) lw[nt] = fvec[4 * E + 16 * nt + r], lb[nt] = fvec[5 * E + 16 * nt + r];
+      if (!(skip & 2)) layer_norm_tile(h, lw, lb, eps);  // block pre-LN
+      // the window's last token (action token len - 1): its residual stream is parked for tail_batch
+      if (job == qjob) {
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const float4 *>(wvF + ((4 * nt + ks) * 64 + lane) * 4);
+        for (int i = 0; i < 4; ++i) {
+          if (16 * mt + 4 * q + i == len - 1) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-              kv[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], __builtin_bit_cast(float4, wk[nt][ks])[c], kv[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-              kv[4 + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], bv[nt][c], kv[4 + nt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) pend_x[nslot * E + 16 * nt + r] = x[nt][i];
           }
+        }
+      }
+      // h -> A fragments through the job's own V rows (token j of the tile -> row 2 (16 mt + j) + kind)
+      float *scr = Vs + (size_t)(2 * 16 * mt + kind) * VLD;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (16 * mt + 4 * q + i < ql) scr[(size_t)(4 * q + i) * 2 * VLD + 16 * nt + r] = h[nt][i];
+      // same wave, LDS operations execute in order: only the compiler must keep the order
+      asm volatile("" ::: "memory");
+      uint4 ha[4];
+      const int rr = 16 * mt + r < ql ? r : 0;  // rows past the LDS image (never stored) re-read row 0
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        ha[ks] = *reinterpret_cast<const uint4 *>(scr + (size_t)rr * 2 * VLD + 16 * ks + 4 * q);
+      asm volatile("" ::: "memory");  // the V rows written below are the scratch read above
+      if (job == qjob) {
+        // queries of the tile (rows 0..63 of attention.in_linear), B fragments from global / L2;
+        // only the last token's row is kept, rounded to bf16 (ops.py:74)
+        f32x4 qa[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const float bias = W.qkv_b[16 * nt + r];
+          qa[nt] = f32x4{bias, bias, bias, bias};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          uint4 bw[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) bw[nt] = ldg16(W.qkv_w + (size_t)(16 * nt + r) * E + 16 * ks + 4 * q);
+          const float4 af = __builtin_bit_cast(float4, ha[ks]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+              qa[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], __builtin_bit_cast(float4, bw[nt])[c], qa[nt], 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int k = 16 * mt + 4 * q + i;
-          if (k < len && !(skip & 8)) {
-            const int t = 2 * k + kind;
+          if (16 * mt + 4 * q + i == len - 1) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-              Kb[(size_t)t * KLD + 16 * nt + r] = f2bf(kv[nt][i] + bkv[nt]);
-              Vs[(size_t)t * VLD + 16 * nt + r] = kv[4 + nt][i] + bkv[4 + nt];
-            }
+            for (int nt = 0; nt < 4; ++nt) qlast[16 * nt + r] = rbf(qa[nt][i]);
+          }
+        }
+      }
+      f32x4 kv[8];
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) kv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // component-major: the four K = 4 MFMAs of one fragment pair accumulate into the same
+      // registers; issuing the other seven n-tiles between them hides the dependent latency
+#pragma unroll
+      for (int ks = 0; ks < ((skip & 16) ? 0 : 4); ++ks) {
+        const float4 af = __builtin_bit_cast(float4, ha[ks]);
+        float4 bv[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const float4 *>(wvF + ((4 * nt + ks) * 64 + lane) * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            kv[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], __builtin_bit_cast(float4, wk[nt][ks])[c], kv[nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            kv[4 + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], bv[nt][c], kv[4 + nt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = 16 * mt + 4 * q + i;
+        if (k < len && !(skip & 8)) {
+          const int t = 2 * k + kind;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            Kb[(size_t)t * KLD + 16 * nt + r] = f2bf(kv[nt][i] + bkv[nt]);
+            Vs[(size_t)t * VLD + 16 * nt + r] = kv[4 + nt][i] + bkv[4 + nt];
           }
         }
       }
@@ -563,7 +543,7 @@ size_t pt_smem_bytes(const iqlhip_pt_weights &W, int ql) {
   const size_t ks = (size_t)round_up(W.state_dim, 16) + round_up(W.action_dim, 16);
   return Tmax * VLD * 4 + Tmax * KLD * 2 + ks * E * 4 + 4 * 4 * 64 * 16 +
          (E + PT_WAVES * E + 2 * PT_WAVES * 16 + round_up((int)Tmax * W.num_heads, 4) + 6 * E + PT_SLOTS * E +
-          2 * PT_SLOTS * VLD + PT_SLOTS * (W.inter_dim + 4) + 2 * ((ql + 15) / 16)) * 4 + 64;
+          2 * PT_SLOTS * VLD + PT_SLOTS * (W.inter_dim + 4)) * 4 + 64;
 }
 
 hipError_t launch_pt(const iqlhip_pt_weights &W, const float *obs, const float *act, int64_t n_rows,
