@@ -33,10 +33,10 @@
 namespace iqlhip {
 
 constexpr int E = 64;
-constexpr int PT_WAVES = 8;
+constexpr int PT_WAVES = 16;  // 1024 threads: four waves per SIMD, <= 128 VGPRs each
 constexpr int VLD = E + 4;  // row stride of the V rows (floats): conflict-free A-fragment reads; column 64 holds 1
 constexpr int KLD = E + 8;  // row stride of the bf16 K rows (144 B): conflict-free 16-byte B-fragment reads
-constexpr int PT_SLOTS = 8; // windows whose last-token MLP is batched (= PT_WAVES: one final LayerNorm per wave)
+constexpr int PT_SLOTS = 8;   // windows whose last-token tail is batched (<= PT_WAVES: one final LayerNorm per wave)
 
 __device__ __forceinline__ float wave_sum(float v) { return lane_sum<64>(v); }
 __device__ __forceinline__ float seg_sum(float v, int width) { return lane_sum_rt(v, width); }  // pow2 groups
@@ -96,19 +96,25 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
   const int nks_s = round_up(S, 16) / 16, nks_a = round_up(A, 16) / 16;
   // ---- LDS carve ----
   float *Vs = reinterpret_cast<float *>(smem);                          // [Tmax][VLD]
-  uint16_t *Kb = reinterpret_cast<uint16_t *>(Vs + (size_t)Tmax * VLD);  // [Tmax][KLD] bf16
-  float *wsF = reinterpret_cast<float *>(Kb + (size_t)Tmax * KLD);         // fragment-major [64][16 nks_s]
+  const size_t vs_floats = (size_t)Tmax * VLD > (size_t)4 * PT_SLOTS * E ? (size_t)Tmax * VLD : (size_t)4 * PT_SLOTS * E;
+  uint16_t *Kb = reinterpret_cast<uint16_t *>(Vs + vs_floats);           // [Tmax][KLD] bf16
+  const size_t kb_floats = (size_t)Tmax * KLD / 2 > (size_t)PT_SLOTS * (I + 4) ? (size_t)Tmax * KLD / 2 : (size_t)PT_SLOTS * (I + 4);
+  float *wsF = reinterpret_cast<float *>(Kb) + kb_floats;         // fragment-major [64][16 nks_s]
   float *waF = wsF + nks_s * 16 * E;                                     // fragment-major [64][16 nks_a]
-  float *wvF = waF + nks_a * 16 * E;                                     // [4 nt][4 ks][64 lanes][4] value projection
-  float *qlast = wvF + 4 * 4 * 64 * 4;                                   // [64] last token's query (bf16 values)
-  float *part = qlast + E;                                               // [PT_WAVES][64] cross-wave partials
+  float *wkvF = waF + nks_a * 16 * E;                                    // [8 nt][4 ks][64 lanes][4] K | V projection
+  float *qlast = wkvF + 8 * 4 * 64 * 4;                                  // [64] last token's query (bf16 values)
+  float *hlast = qlast + E;                                              // [64] last token's block input LN0(x)
+  int *qflag = reinterpret_cast<int *>(hlast + E);                       // [4] hand-over flag of hlast (word 0)
+  float *part = hlast + E + 4;                                              // [PT_WAVES][64] cross-wave partials
   float *stat = part + PT_WAVES * E;                                     // [PT_WAVES][16 heads] x 2
   float *lg = stat + 2 * PT_WAVES * 16;                                  // [Tmax][NH] logits
-  float *fvec = lg + round_up(Tmax * NH, 4);                             // [6][64] per-feature vectors
-  float *pend_x = fvec + 6 * E;                                          // [PT_SLOTS][64] residual stream of parked windows
+  float *fvec = lg + round_up(Tmax * NH, 4);                             // [8][64] per-feature vectors
+  float *pend_x = fvec + 8 * E;                                          // [PT_SLOTS][64] residual stream of parked windows
   float *pend_o = pend_x + PT_SLOTS * E;                                 // [PT_SLOTS][VLD] attention output
   float *pend_h = pend_o + PT_SLOTS * VLD;                               // [PT_SLOTS][VLD] LN1(x1)
-  float *hidb = pend_h + PT_SLOTS * VLD;                                 // [PT_SLOTS][I + 4] MLP hidden
+  // [PT_SLOTS][I + 4] MLP hidden, on the K rows: tail_batch runs between a window's attention and
+  // the next window's token phase, when no key is live (the region is the larger of the two)
+  float *hidb = reinterpret_cast<float *>(Kb);
 
   // ---- weights that stay on chip for the whole queue ----
   // embedding weights as MFMA B fragments (common.h fidx): element (feature f, input k), zero padded
@@ -120,34 +126,25 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
     const int k = e / E, f = e - k * E;
     waF[fidx<P>(f, k, nks_a)] = k < A ? W.action_wT[(size_t)k * E + f] : 0.f;
   }
-  // K | V projection (rows 64..191 of attention.in_linear.weight [192][64]) as B fragments, 4
-  // k-steps of 16: the key rows (n-tile nt -> key features 16 nt..) live in 64 VGPRs for the whole
-  // kernel, the value rows in LDS, one 16-byte fragment per (n-tile, k-step, lane)
-  uint4 wk[4][4];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      wk[nt][ks] = ldg16(W.qkv_w + (size_t)(E + 16 * nt + r) * E + 16 * ks + 4 * q);
-  for (int f = wave; f < 16; f += PT_WAVES)  // f = 4 nt + ks
-    *reinterpret_cast<uint4 *>(wvF + (f * 64 + lane) * 4) =
-        ldg16(W.qkv_w + (size_t)(2 * E + 16 * (f >> 2) + r) * E + 16 * (f & 3) + 4 * q);
-  float bkv[8];
-#pragma unroll
-  for (int nt = 0; nt < 8; ++nt) bkv[nt] = W.qkv_b[E + 16 * nt + r];
+  // K | V projection (rows 64..191 of attention.in_linear.weight [192][64]) as B fragments in
+  // LDS, one 16-byte fragment per (n-tile, k-step, lane): n-tile nt < 4 -> key features 16 nt..,
+  // nt >= 4 -> value features; 4 k-steps of 16
+  for (int f = wave; f < 32; f += PT_WAVES)  // f = 4 nt + ks
+    *reinterpret_cast<uint4 *>(wkvF + (f * 64 + lane) * 4) =
+        ldg16(W.qkv_w + (size_t)(E + 16 * (f >> 2) + r) * E + 16 * (f & 3) + 4 * q);
   // V rows start finite (rows past a window's length are multiplied by zero weights), column 64 = 1
   // (the softmax denominator falls out of the P.V product), columns 65..67 = 0: never written again
   for (int e = tid; e < Tmax * VLD; e += 64 * PT_WAVES) Vs[e] = (e % VLD) == E ? 1.f : 0.f;
   for (int e = tid; e < Tmax * KLD / 2; e += 64 * PT_WAVES) reinterpret_cast<uint32_t *>(Kb)[e] = 0u;
+  if (tid < 4) qflag[tid] = 0;
   // per-feature vectors of the token jobs (read from LDS in the C layout: feature 16 nt + r)
   if (tid < E) {
     fvec[tid] = W.state_b[tid], fvec[E + tid] = W.action_b[tid];
     fvec[2 * E + tid] = W.sln_w[tid], fvec[3 * E + tid] = W.sln_b[tid];
     fvec[4 * E + tid] = W.ln0_w[tid], fvec[5 * E + tid] = W.ln0_b[tid];
+    fvec[6 * E + tid] = W.qkv_b[E + tid], fvec[7 * E + tid] = W.qkv_b[2 * E + tid];  // key / value bias
   }
   // one value per lane (feature = lane) for the last-token phase
-  const float lfw = W.lnf_w[lane], lfb = W.lnf_b[lane];
-  const float pw = W.pref_w_last[lane];
   const float eps = W.eps;
   const float inv_sqrt_hd = 1.0f / sqrtf((float)HD);
   __syncthreads();
@@ -155,122 +152,103 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
   // ---- everything behind the attention of the parked tokens (slots < n) ----
   // Slots are the M rows of 16-row MFMA tiles (rows >= PT_SLOTS alias rows 0..7: their results are
   // dropped).  B fragments come straight from the torch-layout weights ([out][in]: 16 B per lane).
-  //   x1 = x + o . Wo^T + b, h1 = LN1(x1)            [16 x 64] . [64 x 64], wave 0, LN in the C layout
-  //   hidden = relu(h1 . Win^T + b)                  [16 x 64] . [64 x I], n-tiles over the waves
-  //   x2 = x1 + hidden . Wout^T + b                  [16 x I] . [I x 64], one n-tile per wave 0..3
-  //   out = value head(LNf(x2))                      one slot per wave
+  // Every stage is spread over the waves so that no wave holds more than a few fragments:
+  //   S1  x1 = x + o . Wo^T + b                     [16 x 64] . [64 x 64], one n-tile per wave 0..3
+  //   S2  h1 = LN1(x1)                              one slot per wave
+  //   S3  hidden = relu(h1 . Win^T + b)             [16 x 64] . [64 x I], n-tiles over the waves
+  //   S4  hidden . Wout^T                           [16 x I] . [I x 64], (n-tile, K quarter) per wave
+  //   S5  out = value head(LNf(x1 + S4 + b))        one slot per wave
+  // The key / value rows are dead here: K holds the hidden tile, V the K-split partial sums.
   const int ldh = I + 4;
+  float *ksplit = Vs;  // [4 K quarters][PT_SLOTS][64]
   auto tail_batch = [&](int n, int64_t first) {
-    __syncthreads();  // pend_x / pend_o of every slot written
-    if (wave == 0) {
-      f32x4 oa[4], x1[4];
+    __syncthreads();  // pend_x / pend_o of every slot written; keys and values no longer read
+    if (wave < 4) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      uint4 bw[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        oa[ks] = *reinterpret_cast<const f32x4 *>(pend_o + (r & (PT_SLOTS - 1)) * VLD + 16 * ks + 4 * q);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const float bias = W.attn_out_b[16 * nt + r];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x1[nt][i] = bias + pend_x[((4 * q + i) & (PT_SLOTS - 1)) * E + 16 * nt + r];
-      }
+      for (int ks = 0; ks < 4; ++ks) bw[ks] = ldg16(W.attn_out_w + (size_t)(16 * wave + r) * E + 16 * ks + 4 * q);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        uint4 bw[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bw[nt] = ldg16(W.attn_out_w + (size_t)(16 * nt + r) * E + 16 * ks + 4 * q);
+        const f32x4 oa = *reinterpret_cast<const f32x4 *>(pend_o + (r & (PT_SLOTS - 1)) * VLD + 16 * ks + 4 * q);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            x1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[ks][c], __builtin_bit_cast(float4, bw[nt])[c], x1[nt], 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[c], __builtin_bit_cast(float4, bw[ks])[c], acc, 0, 0, 0);
       }
-      float lw[4], lb[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) lw[nt] = W.ln1_w[16 * nt + r], lb[nt] = W.ln1_b[16 * nt + r];
-      f32x4 h1[4] = {x1[0], x1[1], x1[2], x1[3]};
-      layer_norm_tile(h1, lw, lb, eps);
-      asm volatile("" ::: "memory");  // pend_x was read above by this wave: keep the order
       if (q < PT_SLOTS / 4) {
+        const float bias = W.attn_out_b[16 * wave + r];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            pend_x[(4 * q + i) * E + 16 * nt + r] = x1[nt][i];
-            pend_h[(4 * q + i) * VLD + 16 * nt + r] = h1[nt][i];
-          }
+        for (int i = 0; i < 4; ++i) pend_x[(4 * q + i) * E + 16 * wave + r] += acc[i] + bias;
       }
     }
+    __syncthreads();
+    if (wave < PT_SLOTS)
+      pend_h[wave * VLD + lane] = layer_norm(pend_x[wave * E + lane], W.ln1_w[lane], W.ln1_b[lane], eps);
     __syncthreads();
     {
       f32x4 ha[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
         ha[ks] = *reinterpret_cast<const f32x4 *>(pend_h + (r & (PT_SLOTS - 1)) * VLD + 16 * ks + 4 * q);
-      for (int nt0 = wave; nt0 < I / 16; nt0 += 2 * PT_WAVES) {
-        // two n-tiles per pass: independent accumulators hide the dependent MFMA latency
-        const int nt1 = nt0 + PT_WAVES;
-        const bool two = nt1 < I / 16;
-        uint4 b0[4], b1[4];
+      for (int nt = wave; nt < I / 16; nt += PT_WAVES) {
+        uint4 bw[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          b0[ks] = ldg16(W.mlp_in_w + (size_t)(16 * nt0 + r) * E + 16 * ks + 4 * q);
-          b1[ks] = ldg16(W.mlp_in_w + (size_t)(16 * (two ? nt1 : nt0) + r) * E + 16 * ks + 4 * q);
-        }
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < 4; ++ks) bw[ks] = ldg16(W.mlp_in_w + (size_t)(16 * nt + r) * E + 16 * ks + 4 * q);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ks][c], __builtin_bit_cast(float4, b0[ks])[c], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ks][c], __builtin_bit_cast(float4, b1[ks])[c], acc1, 0, 0, 0);
-          }
+          for (int c = 0; c < 4; ++c)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ks][c], __builtin_bit_cast(float4, bw[ks])[c], acc, 0, 0, 0);
         if (q < PT_SLOTS / 4) {
-          const float bi0 = W.mlp_in_b[16 * nt0 + r], bi1 = W.mlp_in_b[16 * (two ? nt1 : nt0) + r];
+          const float bi = W.mlp_in_b[16 * nt + r];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            hidb[(4 * q + i) * ldh + 16 * nt0 + r] = fmaxf(acc0[i] + bi0, 0.f);
-            if (two) hidb[(4 * q + i) * ldh + 16 * nt1 + r] = fmaxf(acc1[i] + bi1, 0.f);
-          }
+          for (int i = 0; i < 4; ++i) hidb[(4 * q + i) * ldh + 16 * nt + r] = fmaxf(acc[i] + bi, 0.f);
         }
       }
     }
     __syncthreads();
-    if (wave < 4) {
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      const float *wrow = W.mlp_out_w + (size_t)(16 * wave + r) * I + 4 * q;
-      const float *arow = hidb + (r & (PT_SLOTS - 1)) * ldh + 4 * q;
-      for (int ks0 = 0; ks0 < I / 16; ks0 += 8) {
-        uint4 bfr[8];
+    {
+      // wave -> (n-tile wave & 3, K quarter wave >> 2); a quarter is I / 64 k-steps of 16
+      const int nt = wave & 3, kq = wave >> 2, nkq = I / 64;
+      const float *wrow = W.mlp_out_w + (size_t)(16 * nt + r) * I + 16 * kq * nkq + 4 * q;
+      const float *arow = hidb + (r & (PT_SLOTS - 1)) * ldh + 16 * kq * nkq + 4 * q;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int ks0 = 0; ks0 < nkq; ks0 += 4) {
+        uint4 bw[4];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) bfr[kk] = ldg16(wrow + 16 * (ks0 + kk));
+        for (int kk = 0; kk < 4; ++kk) bw[kk] = ldg16(wrow + 16 * (ks0 + kk));
 #pragma unroll
-        for (int kk = 0; kk < 8; kk += 2) {
-          const f32x4 a0 = *reinterpret_cast<const f32x4 *>(arow + 16 * (ks0 + kk));
-          const f32x4 a1 = *reinterpret_cast<const f32x4 *>(arow + 16 * (ks0 + kk + 1));
+        for (int kk = 0; kk < 4; ++kk) {
+          const f32x4 av = *reinterpret_cast<const f32x4 *>(arow + 16 * (ks0 + kk));
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], __builtin_bit_cast(float4, bfr[kk])[c], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], __builtin_bit_cast(float4, bfr[kk + 1])[c], acc1, 0, 0, 0);
-          }
+          for (int c = 0; c < 4; ++c)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], __builtin_bit_cast(float4, bw[kk])[c], acc, 0, 0, 0);
         }
       }
       if (q < PT_SLOTS / 4) {
-        const float bo2 = W.mlp_out_b[16 * wave + r];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          part[(4 * q + i) * E + 16 * wave + r] = (acc0[i] + acc1[i]) + bo2 + pend_x[(4 * q + i) * E + 16 * wave + r];
+        for (int i = 0; i < 4; ++i) ksplit[(kq * PT_SLOTS + 4 * q + i) * E + 16 * nt + r] = acc[i];
       }
     }
     __syncthreads();
-    if (wave < n) {  // PT_SLOTS == PT_WAVES: slot = wave, feature = lane
-      const float y = layer_norm(part[wave * E + lane], lfw, lfb, eps);  // gpt.layer_norm
-      const float v = wave_sum(y * pw) + W.pref_b_last;
+    if (wave < n) {  // slot = wave, feature = lane
+      float x2 = pend_x[wave * E + lane] + W.mlp_out_b[lane];
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) x2 += ksplit[(kq * PT_SLOTS + wave) * E + lane];
+      const float y = layer_norm(x2, W.lnf_w[lane], W.lnf_b[lane], eps);  // gpt.layer_norm
+      const float v = wave_sum(y * W.pref_w_last[lane]) + W.pref_b_last;
       if (lane == 0) out[first + (int64_t)wave * gridDim.x] = v;
     }
     __syncthreads();  // LDS is reused by the next window
+    // the first V rows served as scratch: restore what the attention relies on and the token phase
+    // never writes (column 64 = 1, 65..67 = 0); the other columns are rewritten before they are read
+    for (int e = tid; e < 4 * ((4 * PT_SLOTS * E + VLD - 1) / VLD); e += 64 * PT_WAVES)
+      if ((e >> 2) < Tmax) Vs[(e >> 2) * VLD + E + (e & 3)] = (e & 3) == 0 ? 1.f : 0.f;
   };
   int nslot = 0;
   int64_t batch_first = 0;
+  int seq = 0;  // window counter of this work-group: the value the hand-over flag takes
 
   for (int64_t win = blockIdx.x; win < n_win; win += gridDim.x) {
     const int64_t start = win_start[win];
@@ -279,11 +257,12 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
     const int T = 2 * len;
     const int nmt = (len + 15) >> 4;  // 16-token tiles per kind
     // ================= every token: embedding, LayerNorms, key / value =================
-    // The job of the last action tile also projects the queries: it trades places with the job
-    // of the last wave's first round (a wave with one job when there are <= 2 PT_WAVES - 2 jobs).
-    const int njobs = 2 * nmt, qjob = njobs - 1, qslot = qjob < PT_WAVES - 1 ? qjob : PT_WAVES - 1;
-    for (int jslot = wave; jslot < njobs; jslot += PT_WAVES) {
-      const int job = jslot == qslot ? qjob : (jslot == qjob ? qslot : jslot);
+    // One job = 16 tokens of one kind; with <= 16 jobs (query_length <= 128) every wave has at
+    // most one.  The job of the last action tile hands the last token's block input to the
+    // query wave (below) through LDS.
+    ++seq;
+    const int njobs = 2 * nmt, qjob = njobs - 1;
+    for (int job = wave; job < njobs; job += PT_WAVES) {
       const int kind = job >= nmt ? 1 : 0;  // 0: state tokens, 1: action tokens
       const int mt = kind ? job - nmt : job;
       const float *src = kind ? act : obs;
@@ -351,9 +330,12 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
         for (int i = 0; i < 4; ++i) {
           if (16 * mt + 4 * q + i == len - 1) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) pend_x[nslot * E + 16 * nt + r] = x[nt][i];
+            for (int nt = 0; nt < 4; ++nt) pend_x[nslot * E + 16 * nt + r] = x[nt][i], hlast[16 * nt + r] = h[nt][i];
           }
         }
+        // hand the block input of the last token to the query wave: data first, then the flag
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(qflag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       // h -> A fragments through the job's own V rows (token j of the tile -> row 2 (16 mt + j) + kind)
       float *scr = Vs + (size_t)(2 * 16 * mt + kind) * VLD;
@@ -370,54 +352,26 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
       for (int ks = 0; ks < 4; ++ks)
         ha[ks] = *reinterpret_cast<const uint4 *>(scr + (size_t)rr * 2 * VLD + 16 * ks + 4 * q);
       asm volatile("" ::: "memory");  // the V rows written below are the scratch read above
-      if (job == qjob) {
-        // queries of the tile (rows 0..63 of attention.in_linear), B fragments from global / L2;
-        // only the last token's row is kept, rounded to bf16 (ops.py:74)
-        f32x4 qa[4];
+      // keys (half 0), then values (half 1): four n-tiles at a time bound the live B fragments;
+      // component-major: the four K = 4 MFMAs of one fragment pair accumulate into the same
+      // registers, the other three n-tiles issue between them (128 cycles vs the 40 of latency)
+      f32x4 kv[8];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const float bias = W.qkv_b[16 * nt + r];
-          qa[nt] = f32x4{bias, bias, bias, bias};
-        }
+      for (int nt = 0; nt < 8; ++nt) kv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          uint4 bw[4];
+      for (int half = 0; half < 2; ++half) {
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) bw[nt] = ldg16(W.qkv_w + (size_t)(16 * nt + r) * E + 16 * ks + 4 * q);
+        for (int ks = 0; ks < ((skip & 16) ? 0 : 4); ++ks) {
           const float4 af = __builtin_bit_cast(float4, ha[ks]);
+          float4 bw[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            bw[nt] = *reinterpret_cast<const float4 *>(wkvF + ((4 * (4 * half + nt) + ks) * 64 + lane) * 4);
 #pragma unroll
           for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-              qa[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], __builtin_bit_cast(float4, bw[nt])[c], qa[nt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (16 * mt + 4 * q + i == len - 1) {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) qlast[16 * nt + r] = rbf(qa[nt][i]);
-          }
-        }
-      }
-      f32x4 kv[8];
-#pragma unroll
-      for (int nt = 0; nt < 8; ++nt) kv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // component-major: the four K = 4 MFMAs of one fragment pair accumulate into the same
-      // registers; issuing the other seven n-tiles between them hides the dependent latency
-#pragma unroll
-      for (int ks = 0; ks < ((skip & 16) ? 0 : 4); ++ks) {
-        const float4 af = __builtin_bit_cast(float4, ha[ks]);
-        float4 bv[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const float4 *>(wvF + ((4 * nt + ks) * 64 + lane) * 4);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            kv[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], __builtin_bit_cast(float4, wk[nt][ks])[c], kv[nt], 0, 0, 0);
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            kv[4 + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], bv[nt][c], kv[4 + nt], 0, 0, 0);
+              kv[4 * half + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], bw[nt][c], kv[4 * half + nt], 0, 0, 0);
         }
       }
 #pragma unroll
@@ -427,11 +381,31 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
           const int t = 2 * k + kind;
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
-            Kb[(size_t)t * KLD + 16 * nt + r] = f2bf(kv[nt][i] + bkv[nt]);
-            Vs[(size_t)t * VLD + 16 * nt + r] = kv[4 + nt][i] + bkv[4 + nt];
+            Kb[(size_t)t * KLD + 16 * nt + r] = f2bf(kv[nt][i] + fvec[6 * E + 16 * nt + r]);
+            Vs[(size_t)t * VLD + 16 * nt + r] = kv[4 + nt][i] + fvec[7 * E + 16 * nt + r];
           }
         }
       }
+    }
+    if (wave == PT_WAVES - 1) {
+      // ---- the last token's query (rows 0..63 of attention.in_linear): lane = feature, this
+      // lane's weight row requested before the wait (64 registers nothing else needs here), the
+      // dot product in input order; rounded to bf16 (ops.py:74) ----
+      uint4 wq[16];
+#pragma unroll
+      for (int g = 0; g < 16; ++g) wq[g] = ldg16(W.qkv_w + (size_t)lane * E + 4 * g);
+      float acc = W.qkv_b[lane];
+      while (__hip_atomic_load(qflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
+        __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float4 hv = *reinterpret_cast<const float4 *>(hlast + 4 * g);
+        const float4 wv = __builtin_bit_cast(float4, wq[g]);
+        acc = fmaf(hv.x, wv.x, acc), acc = fmaf(hv.y, wv.y, acc);
+        acc = fmaf(hv.z, wv.z, acc), acc = fmaf(hv.w, wv.w, acc);
+      }
+      qlast[lane] = rbf(acc);
     }
     __syncthreads();
     // ================= last token: query, attention over all keys =================
@@ -541,9 +515,12 @@ __global__ __launch_bounds__(64 * PT_WAVES) void k_pt_relabel(const iqlhip_pt_we
 size_t pt_smem_bytes(const iqlhip_pt_weights &W, int ql) {
   const size_t Tmax = 2 * (size_t)ql;
   const size_t ks = (size_t)round_up(W.state_dim, 16) + round_up(W.action_dim, 16);
-  return Tmax * VLD * 4 + Tmax * KLD * 2 + ks * E * 4 + 4 * 4 * 64 * 16 +
-         (E + PT_WAVES * E + 2 * PT_WAVES * 16 + round_up((int)Tmax * W.num_heads, 4) + 6 * E + PT_SLOTS * E +
-          2 * PT_SLOTS * VLD + PT_SLOTS * (W.inter_dim + 4)) * 4 + 64;
+  const size_t kb = Tmax * KLD * 2 > (size_t)PT_SLOTS * (W.inter_dim + 4) * 4 ? Tmax * KLD * 2
+                                                                           : (size_t)PT_SLOTS * (W.inter_dim + 4) * 4;
+  const size_t vs = Tmax * VLD * 4 > (size_t)4 * PT_SLOTS * E * 4 ? Tmax * VLD * 4 : (size_t)4 * PT_SLOTS * E * 4;
+  return vs + kb + ks * E * 4 + 8 * 4 * 64 * 16 +
+         (2 * E + 4 + PT_WAVES * E + 2 * PT_WAVES * 16 + round_up((int)Tmax * W.num_heads, 4) + 8 * E + PT_SLOTS * E +
+          2 * PT_SLOTS * VLD) * 4 + 64;
 }
 
 hipError_t launch_pt(const iqlhip_pt_weights &W, const float *obs, const float *act, int64_t n_rows,
@@ -554,7 +531,7 @@ hipError_t launch_pt(const iqlhip_pt_weights &W, const float *obs, const float *
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   // persistent work-groups: as many as stay resident
-  const int per_cu = 1;  // 8 waves of ~250 VGPRs: one work-group per CU
+  const int per_cu = 1;  // 16 waves, ~150 KB of LDS: one work-group per CU
   int64_t grid = (int64_t)cus * per_cu;
   if (n_win < grid) grid = n_win;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pt_relabel),
