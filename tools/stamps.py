@@ -25,13 +25,29 @@ buf = ia.ReplayBuffer(bench.S_DIM, bench.A_DIM, 200_000, dev)
 buf.load_d4rl_dataset(data)
 prec = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "bf16"
 tr = bench.build_trainer(ia, torch, dev, 1, prec)
-tr.train_steps(buf, 200, bench.BATCH, return_losses=False, graph_unroll=0)
+# STAMP_GROUP=K: the stamped trainer is member 0 of a seed group of K (one launch sequence,
+# gridDim.y = K): the timeline of ITS work-groups inside the group launches
+_K = int(os.environ.get("STAMP_GROUP", "1"))
+grp = None
 dbg = torch.zeros((3, 512, 8, 2), dtype=torch.int64, device=dev)
-_lib.check(lib.iqlhip_trainer_set_debug(tr._handle, C.c_void_p(dbg.data_ptr())))
+if _K > 1:
+    # the group copies its members' descriptors when it is created: attach the buffer first
+    tr._ensure_handle(bench.BATCH)
+    _lib.check(lib.iqlhip_trainer_set_debug(tr._handle, C.c_void_p(dbg.data_ptr())))
+    grp = ia.SeedGroup([tr] + [bench.build_trainer(ia, torch, dev, 1 + i, prec) for i in range(1, _K)], mode="group")
+    grp.train_steps(buf, 200, bench.BATCH, graph_unroll=0)
+    torch.cuda.synchronize()
+    dbg.zero_()
+else:
+    tr.train_steps(buf, 200, bench.BATCH, return_losses=False, graph_unroll=0)
+    _lib.check(lib.iqlhip_trainer_set_debug(tr._handle, C.c_void_p(dbg.data_ptr())))
 # STAMP_GRAPH=n: n steps replayed as one hipGraph (the stamps of the LAST step survive): kernel
 # starts in steady state instead of after a host-side gap
 _g = int(os.environ.get("STAMP_GRAPH", "0"))
-tr.train_steps(buf, max(_g, 1), bench.BATCH, return_losses=False, graph_unroll=_g)
+if grp is not None:
+    grp.train_steps(buf, max(_g, 1), bench.BATCH, graph_unroll=_g)
+else:
+    tr.train_steps(buf, max(_g, 1), bench.BATCH, return_losses=False, graph_unroll=_g)
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().astype(np.float64)
 names = ["k_forward", "k_backward", "k_update"]
