@@ -130,6 +130,22 @@ __device__ __forceinline__ void store4T(typename Prec<BF16>::T *dst, const float
   }
 }
 
+// relu(round(acc + bias)) of the four batch rows a lane holds for one hidden unit (MFMA C layout),
+// in the compute type.  bf16: relu before the rounding (the same value: rounding is monotone and
+// keeps zero), two values per v_cvt_pk_bf16_f32, no round trip through f32 -- a third of the
+// vector instructions of round -> relu -> convert, and these epilogues are what bounds a forward
+// work-group (one or two waves per SIMD).  u.x = rows 0,1, u.y = rows 2,3.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){lo, hi}, bf16x2));
+}
+__device__ __forceinline__ uint2 relu_bias_bf16x4(const f32x4 &acc, float bias) {
+  const float t0 = fmaxf(acc[0] + bias, 0.f), t1 = fmaxf(acc[1] + bias, 0.f);
+  const float t2 = fmaxf(acc[2] + bias, 0.f), t3 = fmaxf(acc[3] + bias, 0.f);
+  return make_uint2(pk_bf16(t0, t1), pk_bf16(t2, t3));
+}
+
 template <bool BF16>
 __device__ __forceinline__ void load4T(const typename Prec<BF16>::T *src, float v[4]) {
   if constexpr (BF16) {
@@ -570,6 +586,8 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
         }
       }
     }
+    bool lean = false;
+    if constexpr (BF16) lean = !N.dropout;  // (wave-uniform) see relu_bias_bf16x4
 #pragma unroll
     for (int jj = 0; jj < TPW; ++jj) {
       const int tile = wave * TPW + jj;
@@ -577,6 +595,22 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
       const float bias = P::round(bias1[jj]);
       // the part that owns this tile's features stores them for the backward pass
       const bool mine = N.train_slot >= 0 && (tile * SPL) / (4 * TPW) == part;
+      if (lean) {
+        if constexpr (BF16) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const int row0 = slab * ROWS + 16 * m;
+            const uint2 u = relu_bias_bf16x4(acc[m][jj], bias);
+            T *hrow = h1 + (16 * m + 4 * q) * HP + col;
+            hrow[0] = (T)(u.x & 0xffff), hrow[HP] = (T)(u.x >> 16);
+            hrow[2 * HP] = (T)(u.y & 0xffff), hrow[3 * HP] = (T)(u.y >> 16);
+            if (mine && row0 < B)
+              stg8(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 0) * H * BP +
+                       fidx<P>(col, row0 + 4 * q, BP / P::KM), u);
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int row0 = slab * ROWS + 16 * m;
@@ -615,23 +649,41 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
     }
     const int col = 16 * tile2 + r;
     const float bias = P::round(bias2);
+    bool lean = false;
+    if constexpr (BF16) lean = !N.dropout;
+    if (lean) {
+      if constexpr (BF16) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int row0 = slab * ROWS + 16 * m;
-      float v[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = fmaxf(P::round(acc[m][i] + bias), 0.f);
-      if (N.dropout) {
-        bool keep[4];
-        dropout_keep4(D, *Ap, step, 1, (row0 >> 2) + q, col, keep);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = keep[i] ? P::round(v[i] * D.drop_scale) : 0.f;
+        for (int m = 0; m < MT; ++m) {
+          const int row0 = slab * ROWS + 16 * m;
+          const uint2 u = relu_bias_bf16x4(acc[m], bias);
+          T *hrow = h2 + (16 * m + 4 * q) * HQP + 16 * wave + r;
+          hrow[0] = (T)(u.x & 0xffff), hrow[HQP] = (T)(u.x >> 16);
+          hrow[2 * HQP] = (T)(u.y & 0xffff), hrow[3 * HQP] = (T)(u.y >> 16);
+          if (N.train_slot >= 0 && row0 < B)
+            stg8(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP +
+                     fidx<P>(col, row0 + 4 * q, BP / P::KM), u);
+        }
       }
+    } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) h2[(16 * m + 4 * q + i) * HQP + 16 * wave + r] = P::from_f32(v[i]);
-      if (N.train_slot >= 0 && row0 < B)
-        store4T<BF16>(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP +
-                          fidx<P>(col, row0 + 4 * q, BP / P::KM), v);
+      for (int m = 0; m < MT; ++m) {
+        const int row0 = slab * ROWS + 16 * m;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(P::round(acc[m][i] + bias), 0.f);
+        if (N.dropout) {
+          bool keep[4];
+          dropout_keep4(D, *Ap, step, 1, (row0 >> 2) + q, col, keep);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = keep[i] ? P::round(v[i] * D.drop_scale) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h2[(16 * m + 4 * q + i) * HQP + 16 * wave + r] = P::from_f32(v[i]);
+        if (N.train_slot >= 0 && row0 < B)
+          store4T<BF16>(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP +
+                            fidx<P>(col, row0 + 4 * q, BP / P::KM), v);
+      }
     }
   }
   __syncthreads();
