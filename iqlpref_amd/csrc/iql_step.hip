@@ -434,7 +434,7 @@ struct FCfg {
   static_assert(HQ == 64, "one 16-column tile per wave and part");
 };
 
-template <bool BF16, int H, int MT>
+template <bool BF16, int H, int MT, int PW>
 __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__ Dp,
                                                  const DevArgs *__restrict__ Ap,
                                                  const DevCtr *__restrict__ Cp, const int nsl_,
@@ -442,7 +442,13 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   using C = FCfg<BF16, H>;
   using P = Prec<BF16>;
   using T = typename P::T;
+  // PW = parts of hidden layer 2 (64 units each) per work-group: 1 for a lone seed (most
+  // work-groups, shortest chains), 2 for seed groups (layer 1 -- whose epilogue is the vector work
+  // that bounds a busy CU -- is recomputed SPL / PW times instead of SPL times).  Every part
+  // still produces its own partial layer-3 plane: the sums the consumer forms are the same.
   constexpr int ROWS = 16 * MT, TPW = C::TPW, SPL = C::SPL, HP = C::HP, HQP = C::HQP;
+  constexpr int NPG = SPL / PW;  // part groups = work-groups per (evaluation, slab)
+  static_assert(SPL % PW == 0 && PW <= 2, "parts per work-group: 1 or 2, dividing the parts");
   // blockIdx.y = seed of a group launch (iqlhip_group_*): the descriptors of the seeds of a
   // group are contiguous arrays; a solo launch has gridDim.y = 1
   Dp += blockIdx.y, Ap += blockIdx.y, Cp += blockIdx.y;
@@ -452,11 +458,11 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   // and with it the address of this work-group's FwdNet, must not wait for a descriptor load)
   const TrainerDesc &D = *Dp;
   const int idx_ = blockIdx.x >> 3;
-  const int per_job = nsl_ * SPL;
+  const int per_job = nsl_ * NPG;
   const int fnet = (idx_ / per_job) * 8 + (blockIdx.x & 7);
   const int rest = idx_ % per_job;
-  const int slab = rest / SPL;
-  const int part = __builtin_amdgcn_readfirstlane(rest % SPL);
+  const int slab = rest / NPG;
+  const int part0 = __builtin_amdgcn_readfirstlane((rest % NPG) * PW);  // first of this work-group's parts
   if (fnet > nfwd_) return;
   if (fnet == nfwd_) {
     // spare XCD slot: one thread prepares this step's Adam coefficients for k_update
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   const int K1P = k1max + P::EPV;
   T *xs = reinterpret_cast<T *>(smem);   // [ROWS][K1P]  layer-1 input
   T *h1 = xs + ROWS * K1P;               // [ROWS][HP]   all of hidden layer 1
-  T *h2 = h1 + ROWS * HP;                // [ROWS][HQP]  this part of hidden layer 2
+  T *h2 = h1 + ROWS * HP;                // [PW][ROWS][HQP]  this work-group's parts of hidden layer 2
   STAMP(0, 0);
 
   // ---- the input rows first (loads return in order): the staged batch, 16 lanes per row,
@@ -508,18 +514,20 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   // the END of a layer and loads return in order.  Uniform (SGPR) bases + one per-lane offset. ----
   const int nk1 = N.k1pad / P::KM;
   const int nt3 = N.out_pad / 16;  // 1 or 2
-  const int tile2 = part * 4 + wave;  // this wave's n-tile of layer 2 (of H / 16)
+  const int tile2 = part0 * 4 + wave;  // this wave's n-tile of layer 2 in part j: tile2 + 4 j
   float bias1[TPW], bias3[2];
   {
     const float *b1w = N.b1 + 16 * (wave * TPW);
 #pragma unroll
     for (int jj = 0; jj < TPW; ++jj) bias1[jj] = ldg(b1w + 16 * jj + r);
   }
-  const float bias2 = ldg(N.b2 + 16 * tile2 + r);
+  float bias2[PW];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) bias2[j] = ldg(N.b2 + 16 * (tile2 + 4 * j) + r);
 #pragma unroll
   for (int jt = 0; jt < 2; ++jt)  // clamped (used for col < out_dim)
     bias3[jt] = ldg(N.b3 + (16 * jt + r < N.out_dim ? 16 * jt + r : N.out_dim - 1));
-  uint4 w1[C::NK1][TPW], w2[C::NK2], w3[C::NK3][2];
+  uint4 w1[C::NK1][TPW], w2[PW][C::NK2], w3[PW][C::NK3][2];
   {
     // (scalar guard: a CU's L1 port moves 64 B / clk, a redundant 1 KiB fragment load costs the
     // work-group 16 cycles of it -- the load phase of this kernel is bound by exactly that)
@@ -532,15 +540,21 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
           w1[ks][jj] = ldg16(W1w + (size_t)(jj * nk1 + ks) * 64 * P::EPV + lane * P::EPV);
       }
     }
-    const T *W2w = reinterpret_cast<const T *>(N.w2c) + (size_t)tile2 * C::NK2 * 64 * P::EPV;
 #pragma unroll
-    for (int ks = 0; ks < C::NK2; ++ks) w2[ks] = ldg16(W2w + ks * 64 * P::EPV + lane * P::EPV);
-    const T *W3w = reinterpret_cast<const T *>(N.w3c) + (size_t)(part * C::NK3) * 64 * P::EPV;
+    for (int j = 0; j < PW; ++j) {
+      const T *W2w = reinterpret_cast<const T *>(N.w2c) + (size_t)(tile2 + 4 * j) * C::NK2 * 64 * P::EPV;
 #pragma unroll
-    for (int ks = 0; ks < C::NK3; ++ks)
+      for (int ks = 0; ks < C::NK2; ++ks) w2[j][ks] = ldg16(W2w + ks * 64 * P::EPV + lane * P::EPV);
+    }
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-        if (jt < nt3) w3[ks][jt] = ldg16(W3w + (size_t)(jt * C::NK2 + ks) * 64 * P::EPV + lane * P::EPV);
+    for (int j = 0; j < PW; ++j) {
+      const T *W3w = reinterpret_cast<const T *>(N.w3c) + (size_t)((part0 + j) * C::NK3) * 64 * P::EPV;
+#pragma unroll
+      for (int ks = 0; ks < C::NK3; ++ks)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+          if (jt < nt3) w3[j][ks][jt] = ldg16(W3w + (size_t)(jt * C::NK2 + ks) * 64 * P::EPV + lane * P::EPV);
+    }
   }
   STAMP(0, 1);
 
@@ -594,7 +608,7 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
       const int col = 16 * tile + r;
       const float bias = P::round(bias1[jj]);
       // the part that owns this tile's features stores them for the backward pass
-      const bool mine = N.train_slot >= 0 && (tile * SPL) / (4 * TPW) == part;
+      const bool mine = N.train_slot >= 0 && ((tile * SPL) / (4 * TPW)) / PW * PW == part0;
       if (lean) {
         if constexpr (BF16) {
 #pragma unroll
@@ -634,44 +648,51 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   __syncthreads();
   STAMP(0, 3);
 
-  // ---- hidden layer 2: this part's 64 features, one n-tile per wave ----
+  // ---- hidden layer 2: 64 features per part, one n-tile per wave and part ----
   {
-    f32x4 acc[MT];
+    f32x4 acc[PW][MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < PW; ++j)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < C::NK2; ++ks) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const uint4 a = *reinterpret_cast<const uint4 *>(h1 + (16 * m + r) * HP + ks * P::KM + P::EPV * q);
-        P::mma(a, w2[ks], acc[m]);
+#pragma unroll
+        for (int j = 0; j < PW; ++j) P::mma(a, w2[j][ks], acc[j][m]);
       }
     }
-    const int col = 16 * tile2 + r;
-    const float bias = P::round(bias2);
     bool lean = false;
     if constexpr (BF16) lean = !N.dropout;
-    if (lean) {
-      if constexpr (BF16) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int row0 = slab * ROWS + 16 * m;
-          const uint2 u = relu_bias_bf16x4(acc[m], bias);
-          T *hrow = h2 + (16 * m + 4 * q) * HQP + 16 * wave + r;
-          hrow[0] = (T)(u.x & 0xffff), hrow[HQP] = (T)(u.x >> 16);
-          hrow[2 * HQP] = (T)(u.y & 0xffff), hrow[3 * HQP] = (T)(u.y >> 16);
-          if (N.train_slot >= 0 && row0 < B)
-            stg8(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP +
-                     fidx<P>(col, row0 + 4 * q, BP / P::KM), u);
+    for (int j = 0; j < PW; ++j) {
+      const int col = 16 * (tile2 + 4 * j) + r;
+      const float bias = P::round(bias2[j]);
+      T *h2j = h2 + j * ROWS * HQP;
+      if (lean) {
+        if constexpr (BF16) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const int row0 = slab * ROWS + 16 * m;
+            const uint2 u = relu_bias_bf16x4(acc[j][m], bias);
+            T *hrow = h2j + (16 * m + 4 * q) * HQP + 16 * wave + r;
+            hrow[0] = (T)(u.x & 0xffff), hrow[HQP] = (T)(u.x >> 16);
+            hrow[2 * HQP] = (T)(u.y & 0xffff), hrow[3 * HQP] = (T)(u.y >> 16);
+            if (N.train_slot >= 0 && row0 < B)
+              stg8(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP +
+                       fidx<P>(col, row0 + 4 * q, BP / P::KM), u);
+          }
         }
+        continue;
       }
-    } else {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int row0 = slab * ROWS + 16 * m;
         float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = fmaxf(P::round(acc[m][i] + bias), 0.f);
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(P::round(acc[j][m][i] + bias), 0.f);
         if (N.dropout) {
           bool keep[4];
           dropout_keep4(D, *Ap, step, 1, (row0 >> 2) + q, col, keep);
@@ -679,7 +700,7 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
           for (int i = 0; i < 4; ++i) v[i] = keep[i] ? P::round(v[i] * D.drop_scale) : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) h2[(16 * m + 4 * q + i) * HQP + 16 * wave + r] = P::from_f32(v[i]);
+        for (int i = 0; i < 4; ++i) h2j[(16 * m + 4 * q + i) * HQP + 16 * wave + r] = P::from_f32(v[i]);
         if (N.train_slot >= 0 && row0 < B)
           store4T<BF16>(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP +
                             fidx<P>(col, row0 + 4 * q, BP / P::KM), v);
@@ -689,24 +710,34 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   __syncthreads();
   STAMP(0, 4);
 
-  // ---- output layer, partial over this part's 64 hidden units: wave m < MT takes row tile m.
-  // No rounding here: the parts are summed in fp32 by the consumer, then rounded once.
-  if (wave < MT) {
-    const int m = wave;
+  // ---- output layer, one partial plane per part (64 hidden units each): the MT x PW (row tile,
+  // part) pairs are dealt over the waves.  No rounding here: the parts are summed in fp32 by
+  // the consumer, then rounded once.
+  for (int pr = wave; pr < MT * PW; pr += 4) {
+    const int m = pr % MT, j = pr / MT;
+    const T *h2j = h2 + j * ROWS * HQP;
     f32x4 acc3[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int ks = 0; ks < C::NK3; ++ks) {
-      const uint4 a = *reinterpret_cast<const uint4 *>(h2 + (16 * m + r) * HQP + ks * P::KM + P::EPV * q);
+      const uint4 a = *reinterpret_cast<const uint4 *>(h2j + (16 * m + r) * HQP + ks * P::KM + P::EPV * q);
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-        if (jt < nt3) P::mma(a, w3[ks][jt], acc3[jt]);
+      for (int jt = 0; jt < 2; ++jt) {
+        if (jt < nt3) {
+          if constexpr (PW == 1) {
+            P::mma(a, w3[0][ks][jt], acc3[jt]);
+          } else {  // (j is wave-uniform: a scalar branch, not a register index)
+            if (j == 0) P::mma(a, w3[0][ks][jt], acc3[jt]);
+            else P::mma(a, w3[PW - 1][ks][jt], acc3[jt]);
+          }
+        }
+      }
     }
-    float *outp = g_outs + (size_t)part * B * OUTW;
+    float *outp = g_outs + (size_t)(part0 + j) * B * OUTW;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       const int col = 16 * jt + r;
       if (jt < nt3 && col < N.out_dim) {
-        const float bias = part == 0 ? P::round(bias3[jt]) : 0.f;
+        const float bias = part0 + j == 0 ? P::round(bias3[jt]) : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = slab * ROWS + 16 * m + 4 * q + i;
@@ -1678,10 +1709,10 @@ size_t infer_smem_bytes(bool bf16, int H, int k1max) {
   const int es = bf16 ? 2 : 4, epv = bf16 ? 8 : 4;
   return (size_t)SLAB * (k1max + epv) * es + 2 * (size_t)SLAB * (H + epv) * es + 4 * 2 * 64 * 4 * 4;
 }
-// k_forward: xs [16 MT][k1max + EPV], h1 [16 MT][H + EPV], h2 [16 MT][64 + EPV]
-size_t fwd_smem_bytes(bool bf16, int H, int k1max, int mt) {
+// k_forward: xs [16 MT][k1max + EPV], h1 [16 MT][H + EPV], h2 [PW][16 MT][64 + EPV]
+size_t fwd_smem_bytes(bool bf16, int H, int k1max, int mt, int pw) {
   const int es = bf16 ? 2 : 4, epv = bf16 ? 8 : 4;
-  return (size_t)16 * mt * ((k1max + epv) + (H + epv) + (64 + epv)) * es;
+  return (size_t)16 * mt * ((k1max + epv) + (H + epv) + pw * (64 + epv)) * es;
 }
 size_t bwd_smem_bytes(bool bf16, int H) {
   const int es = bf16 ? 2 : 4, epv = bf16 ? 8 : 4;
@@ -1701,6 +1732,14 @@ int fwd_row_tiles(int B, int n_seeds) {
   return 1;
 }
 int layer2_parts(int H) { return H >= 256 ? 4 : H / 64; }
+// parts of hidden layer 2 per forward work-group: 2 in a group launch that keeps the chip full
+// anyway (layer 1 and its epilogue are then computed twice per slab instead of four times)
+int fwd_parts_per_wg(int B, int H, int n_seeds) {
+  static const int forced = getenv("IQLHIP_FWD_PW") ? atoi(getenv("IQLHIP_FWD_PW")) : 0;  // A/B knob
+  const int spl = layer2_parts(H);
+  if ((forced == 1 || forced == 2) && spl % forced == 0) return forced;
+  return ((int64_t)B * n_seeds >= 1024 && spl % 2 == 0) ? 2 : 1;
+}
 
 #define DISPATCH_H(BF, HH, CALL)                 \
   do {                                           \
@@ -1718,20 +1757,29 @@ int layer2_parts(int H) { return H >= 256 ? 4 : H / 64; }
 hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
                           const DevCtr *c, int n_seeds, hipStream_t st) {
   const int mt = fwd_row_tiles(D.B, n_seeds), nsl = (D.B + 16 * mt - 1) / (16 * mt);
-  // nfwd evaluations + the spare job, each nsl slabs x SPL parts
-  const int grid = 8 * ((D.nfwd + 1 + 7) / 8) * nsl * layer2_parts(D.H);
-  const size_t sm = fwd_smem_bytes(bf16, D.H, D.k1max, mt);
-#define CALL(BF, HH)                                                                                          \
-  do {                                                                                                        \
-    if (mt == 4)                                                                                              \
-      hipLaunchKernelGGL((k_forward<BF, HH, 4>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsl, D.nfwd); \
-    else if (mt == 2)                                                                                         \
-      hipLaunchKernelGGL((k_forward<BF, HH, 2>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsl, D.nfwd); \
-    else                                                                                                      \
-      hipLaunchKernelGGL((k_forward<BF, HH, 1>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsl, D.nfwd); \
+  const int pw = fwd_parts_per_wg(D.B, D.H, n_seeds);
+  // nfwd evaluations + the spare job, each nsl slabs x (SPL / pw) part groups
+  const int grid = 8 * ((D.nfwd + 1 + 7) / 8) * nsl * (layer2_parts(D.H) / pw);
+  const size_t sm = fwd_smem_bytes(bf16, D.H, D.k1max, mt, pw);
+#define LAUNCH_F(BF, HH, MTV, PWV)                                                                            \
+  hipLaunchKernelGGL((k_forward<BF, HH, MTV, PWV>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsl, D.nfwd)
+#define CALL(BF, HH)                                                   \
+  do {                                                                 \
+    if constexpr (HH >= 128) {                                         \
+      if (pw == 2) {                                                   \
+        if (mt == 4) LAUNCH_F(BF, HH, 4, 2);                           \
+        else if (mt == 2) LAUNCH_F(BF, HH, 2, 2);                      \
+        else LAUNCH_F(BF, HH, 1, 2);                                   \
+        break;                                                         \
+      }                                                                \
+    }                                                                  \
+    if (mt == 4) LAUNCH_F(BF, HH, 4, 1);                               \
+    else if (mt == 2) LAUNCH_F(BF, HH, 2, 1);                          \
+    else LAUNCH_F(BF, HH, 1, 1);                                       \
   } while (0)
   DISPATCH_H(bf16, D.H, CALL);
 #undef CALL
+#undef LAUNCH_F
   return hipGetLastError();
 }
 hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
