@@ -1720,14 +1720,14 @@ size_t bwd_smem_bytes(bool bf16, int H) {
 }
 // batch rows per forward work-group = 16 x this (more rows per work-group = fewer re-reads of
 // the weights; fewer work-groups): 2 for the headline batch 256 (224 work-groups at E = 2)
-// Measured (tools/group_scan.py, IQLHIP_FWD_MT): one seed alone is fastest with 16-row work-groups
-// (448 of them at batch 256: two per CU, whose phases interleave on each SIMD), two seeds with
-// 32 rows, four and more with 64 (fewer, longer work-groups; the weights are re-read less often).
+// Measured (tools/group_scan.py, IQLHIP_FWD_MT / IQLHIP_FWD_PW): one seed alone is fastest with
+// 16-row work-groups (448 of them at batch 256: two per CU, whose phases interleave on each
+// SIMD), two seeds and more with 32 rows; from four seeds on with two layer-2 parts per
+// work-group (K = 8: 154.8k steps/s against 150.2k with 64 rows x one part, 139.7k with 32 x one).
 int fwd_row_tiles(int B, int n_seeds) {
   static const int forced = getenv("IQLHIP_FWD_MT") ? atoi(getenv("IQLHIP_FWD_MT")) : 0;  // A/B knob
   if ((forced == 1 || forced == 2 || forced == 4) && B % (16 * forced) == 0) return forced;
   const int64_t rows = (int64_t)B * n_seeds;
-  if (rows >= 1024 && B % 64 == 0) return 4;
   if (rows >= 512 && B % 32 == 0) return 2;
   return 1;
 }
