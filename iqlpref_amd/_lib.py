@@ -103,6 +103,8 @@ SYMBOLS = {
                                            C.POINTER(P), C.c_int32, P]),
     "iqlhip_group_set_timing": (C.c_int, [P, C.c_int32]),
     "iqlhip_group_get_timing": (C.c_int, [P, C.POINTER(C.c_double * 3), C.POINTER(C.c_int64)]),
+    "iqlhip_stream_create_cu_slice": (C.c_int, [C.POINTER(P), C.c_int32, C.c_int32]),
+    "iqlhip_stream_destroy": (C.c_int, [P]),
     "iqlhip_train_batch": (C.c_int, [P, P, P, P, P, P, P, P, P]),
     "iqlhip_forward": (C.c_int, [P, C.c_int32, P, P, C.c_int64, P, P]),
     "iqlhip_mlp_forward": (C.c_int, [C.POINTER(MlpDesc), P, C.c_int64, C.c_int32, P, C.c_int32, P]),

@@ -1045,6 +1045,25 @@ extern "C" int iqlhip_group_set_timing(iqlhip_group *g, int32_t enable) {
   return 0;
 }
 
+extern "C" int iqlhip_stream_create_cu_slice(void **stream, int32_t slice, int32_t n_slices) {
+  if (!stream || n_slices < 1 || slice < 0 || slice >= n_slices)
+    return fail(IQLHIP_ERR_INVALID, "stream slice %d of %d", slice, n_slices);
+  int dev = 0, cus = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  if (cus < n_slices) return fail(IQLHIP_ERR_INVALID, "%d slices of %d compute units", n_slices, cus);
+  std::vector<uint32_t> mask((cus + 31) / 32, 0u);
+  for (int cu = slice; cu < cus; cu += n_slices) mask[cu >> 5] |= 1u << (cu & 31);
+  hipStream_t st = nullptr;
+  HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+  *stream = st;
+  return 0;
+}
+extern "C" int iqlhip_stream_destroy(void *stream) {
+  if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int iqlhip_group_get_timing(iqlhip_group *g, double avg_ms[3], int64_t *n) {
   if (!g) return fail(IQLHIP_ERR_INVALID, "null group");
   for (int k = 0; k < 3; ++k) {

@@ -12,12 +12,14 @@ is bit-identical to running it alone.  Two execution modes:
     boundaries per seed-step.
 ``mode="streams"``
     every trainer replays its own hipGraph on its own HIP stream; the launches interleave.
-``mode="split"`` (``n_streams=G``)
-    G sub-groups, each stepped by its own launch sequence on its own HIP stream.  While a launch
-    does not fill the chip (K <= 2 seeds per launch: at most two work-groups per CU) the kernels
-    of two sub-groups run side by side -- one's HBM-bound k_update beside the other's
-    latency-bound k_forward: four seeds as 2 x 2 measured 142k steps/s against 119k as one group
-    of four (tools/group_streams.py); larger sub-groups fill the chip and gain nothing.
+``mode="split"`` (``n_streams=G``, default 2)
+    G sub-groups, each stepped by its own launch sequence on its own HIP stream, every stream
+    confined to its own slice of the compute units (CU i belongs to slice i % G,
+    ``iqlhip_stream_create_cu_slice``).  The sub-groups never share a CU, only the memory system:
+    one's HBM-bound k_update runs beside the other's latency-bound k_forward / k_backward.
+    Measured (tools/group_streams.py): 8 seeds as 2 x 4 190k steps/s against 155k as one group of
+    8; 16 seeds as 2 x 8 218k against 166k; 4 seeds as 2 x 2 143k against 119k.  Two slices are the
+    sweet spot (three do not divide the chip's 8 XCDs evenly, four leave each sub-group too few CUs).
 """
 import ctypes as C
 from typing import List, Optional, Sequence, Union
@@ -70,7 +72,7 @@ class SeedGroup:
                 self._children.append(SeedGroup(self.trainers[lo:hi], mode="group"))
                 self._child_slices.append(slice(lo, hi))
                 lo = hi
-            self._streams = [torch.cuda.Stream(device=self._dev) for _ in self._children]
+            self._raw_streams = []
             self._chunk = min(self._chunk, 500)  # short turns keep the queues of all streams fed
 
     def __len__(self):
@@ -104,10 +106,17 @@ class SeedGroup:
         for ch in getattr(self, "_children", []):
             ch.close()
         self._drop_group()
+        raw, self._raw_streams = getattr(self, "_raw_streams", []), []
+        if raw:
+            for st in self._streams:
+                st.synchronize()
+            self._streams = []
+            for st in raw:
+                self._lib.iqlhip_stream_destroy(st)
 
     def __del__(self):
         try:
-            self._drop_group()
+            self.close()
         except Exception:
             pass
 
@@ -181,7 +190,19 @@ class SeedGroup:
             return [torch.cat(o) for o in out]
         return None
 
+    def _ensure_slice_streams(self):
+        if self._raw_streams:
+            return
+        G = len(self._children)
+        with torch.cuda.device(self._dev):
+            for g in range(G):
+                st = C.c_void_p()
+                check(self._lib.iqlhip_stream_create_cu_slice(C.byref(st), g, G))
+                self._raw_streams.append(st)
+        self._streams = [torch.cuda.ExternalStream(st.value, device=self._dev) for st in self._raw_streams]
+
     def _train_split(self, bufs, n_steps, batch_size, idx, keep, return_losses, graph_unroll):
+        self._ensure_slice_streams()
         cur = torch.cuda.current_stream(self._dev)
         for st in self._streams:
             st.wait_stream(cur)
