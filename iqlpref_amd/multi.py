@@ -31,6 +31,25 @@ from ._lib import check, ptr, stream_ptr
 from .iql import ImplicitQLearning, ReplayBuffer
 
 
+# The CU-slice streams of a device are created once per process and shared by every split-mode
+# group: a slice stream created after an earlier one was destroyed landed on the hardware queue
+# of its sibling (both halves of the chip then serialised: 91k instead of 190k steps/s).
+_SLICE_STREAMS = {}
+
+
+def _slice_streams(lib, dev, n_slices: int):
+    key = (torch.device(dev).index or 0, n_slices)
+    if key not in _SLICE_STREAMS:
+        raw = []
+        with torch.cuda.device(dev):
+            for g in range(n_slices):
+                st = C.c_void_p()
+                check(lib.iqlhip_stream_create_cu_slice(C.byref(st), g, n_slices))
+                raw.append(st)
+        _SLICE_STREAMS[key] = (raw, [torch.cuda.ExternalStream(st.value, device=dev) for st in raw])
+    return list(_SLICE_STREAMS[key][1])
+
+
 def _shape_key(t: ImplicitQLearning):
     return (t._state_dim, t._action_dim, t._hidden, t._precision, t._deterministic, t._n_critics,
             bool(t._dropout))
@@ -72,7 +91,6 @@ class SeedGroup:
                 self._children.append(SeedGroup(self.trainers[lo:hi], mode="group"))
                 self._child_slices.append(slice(lo, hi))
                 lo = hi
-            self._raw_streams = []
             self._chunk = min(self._chunk, 500)  # short turns keep the queues of all streams fed
 
     def __len__(self):
@@ -106,13 +124,10 @@ class SeedGroup:
         for ch in getattr(self, "_children", []):
             ch.close()
         self._drop_group()
-        raw, self._raw_streams = getattr(self, "_raw_streams", []), []
-        if raw:
+        if getattr(self, "mode", None) == "split":
             for st in self._streams:
                 st.synchronize()
-            self._streams = []
-            for st in raw:
-                self._lib.iqlhip_stream_destroy(st)
+            self._streams = []  # (the slice streams themselves are shared and stay, see _slice_streams)
 
     def __del__(self):
         try:
@@ -191,15 +206,9 @@ class SeedGroup:
         return None
 
     def _ensure_slice_streams(self):
-        if self._raw_streams:
+        if self._streams:
             return
-        G = len(self._children)
-        with torch.cuda.device(self._dev):
-            for g in range(G):
-                st = C.c_void_p()
-                check(self._lib.iqlhip_stream_create_cu_slice(C.byref(st), g, G))
-                self._raw_streams.append(st)
-        self._streams = [torch.cuda.ExternalStream(st.value, device=self._dev) for st in self._raw_streams]
+        self._streams = _slice_streams(self._lib, self._dev, len(self._children))
 
     def _train_split(self, bufs, n_steps, batch_size, idx, keep, return_losses, graph_unroll):
         self._ensure_slice_streams()
