@@ -77,6 +77,24 @@ static int fail(int code, const char *fmt, ...) {
   } while (0)
 
 extern "C" const char *iqlhip_last_error(void) { return g_err; }
+// One capture-only stream per host thread and device, kept for the life of the process (stream
+// capture is thread-local, nothing ever executes on it).  A stream per trainer / group, created and
+// destroyed with its owner, churned the runtime's hardware queues: CU-slice streams created after
+// such a destroy no longer ran side by side (both halves of the chip serialised).
+static hipError_t capture_stream(hipStream_t *out) {
+  static thread_local hipStream_t pool[64] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!pool[dev]) {
+    e = hipStreamCreateWithFlags(&pool[dev], hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+  }
+  *out = pool[dev];
+  return hipSuccess;
+}
+
 extern "C" int iqlhip_abi_version(void) { return 4; }
 // sha256 prefix of csrc/* + include/iqlhip.h, stamped by iqlpref_amd/build.py: the Python side
 // refuses a library whose tag does not match the sources it sits beside
@@ -213,7 +231,7 @@ struct iqlhip_trainer {
   // hipGraph of `graph_unroll` steps
   hipGraphExec_t gexec = nullptr;
   int graph_unroll = 0;
-  hipStream_t cap_stream = nullptr;  // capture only (the legacy default stream cannot capture)
+  hipStream_t cap_stream = nullptr;  // capture only (the legacy default stream cannot capture); shared, see capture_stream
   // timing
   bool timing = false;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -571,7 +589,6 @@ extern "C" int iqlhip_trainer_destroy(iqlhip_trainer *t) {
   if (!t) return 0;
   if (t->group) return fail(IQLHIP_ERR_INVALID, "trainer is a member of a group: destroy the group first");
   if (t->gexec) (void)hipGraphExecDestroy(t->gexec);
-  if (t->cap_stream) (void)hipStreamDestroy(t->cap_stream);
   for (int k = 0; k < iqlhip_trainer::ARG_RING; ++k) {
     if (t->harg_ev[k]) (void)hipEventDestroy(t->harg_ev[k]);
     if (t->harg[k]) (void)hipHostFree(t->harg[k]);
@@ -728,7 +745,7 @@ static int run_steps(iqlhip_trainer *t, const DevArgs &args_in, int64_t n_steps,
         t->gexec = nullptr;
       }
       hipGraph_t g = nullptr;
-      if (!t->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&t->cap_stream, hipStreamNonBlocking));
+      if (!t->cap_stream) HIP_TRY(capture_stream(&t->cap_stream));
       HIP_TRY(hipStreamBeginCapture(t->cap_stream, hipStreamCaptureModeThreadLocal));
       int rc = 0;
       for (int u = 0; u < graph_unroll && !rc; ++u) rc = enqueue_step(t, t->cap_stream);
@@ -904,7 +921,6 @@ extern "C" int iqlhip_group_destroy(iqlhip_group *g) {
     }
   }
   if (g->gexec) (void)hipGraphExecDestroy(g->gexec);
-  if (g->cap_stream) (void)hipStreamDestroy(g->cap_stream);
   for (auto &e : g->ev)
     if (e) (void)hipEventDestroy(e);
   for (int k = 0; k < iqlhip_group::ARG_RING; ++k) {
@@ -1015,7 +1031,7 @@ extern "C" int iqlhip_group_train_steps(iqlhip_group *g, const iqlhip_replay_vie
         g->gexec = nullptr;
       }
       hipGraph_t gr = nullptr;
-      if (!g->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&g->cap_stream, hipStreamNonBlocking));
+      if (!g->cap_stream) HIP_TRY(capture_stream(&g->cap_stream));
       HIP_TRY(hipStreamBeginCapture(g->cap_stream, hipStreamCaptureModeThreadLocal));
       int rc = 0;
       for (int u = 0; u < graph_unroll && !rc; ++u) rc = group_enqueue_step(g, g->cap_stream);
