@@ -189,6 +189,41 @@ def test_pt_kernel_vs_oracle(S, A, QL, heads):
     np.testing.assert_allclose(got, want, rtol=5e-3, atol=5e-3)
 
 
+@pytest.mark.parametrize("heads,inter,QL", [(8, 512, 12), (1, 256, 20), (16, 256, 7)])
+def test_pt_kernel_many_windows_per_workgroup(heads, inter, QL):
+    """A persistent work-group walks several windows and parks their last tokens in slots of 8
+    (full batches, then a partial one at the end of its queue): every window's value must be the
+    one it gets when it is the only window of its work-group, bit for bit, and match the oracle.
+    Covers 1 / 8 / 16 heads (the block-masked query rows) and a wider MLP.  PARITY UNPINNED."""
+    S, A, max_ep = 7, 3, 64
+    rng = np.random.default_rng(heads)
+    p = ro.make_pt_params(rng, S, A, max_ep, embd=64, pref=8, inter=inter, layers=1)
+    m = make_pt(p, S, A, max_ep, heads, inter)
+    n_rows = 4000
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    n_win = cus * 9 + 5  # nine or ten windows per work-group: one full batch of 8 and a partial one
+    obs = rng.standard_normal((n_rows, S)).astype(np.float32)
+    act = rng.uniform(-1, 1, (n_rows, A)).astype(np.float32)
+    lens = rng.integers(1, QL + 1, n_win).astype(np.int32)
+    starts = rng.integers(0, n_rows - QL, n_win).astype(np.int64)
+    t0 = rng.integers(0, max_ep - QL, n_win).astype(np.int32)
+    dv = lambda x: torch.from_numpy(x).to(DEV)
+    o, a_, st, ln, tt = dv(obs), dv(act), dv(starts), dv(lens), dv(t0)
+    got = m.window_values(o, a_, st, ln, QL, win_t0=tt).cpu().numpy()
+    assert np.isfinite(got).all()
+    alone = np.concatenate([m.window_values(o, a_, st[i:i + 64], ln[i:i + 64], QL, win_t0=tt[i:i + 64]).cpu().numpy()
+                            for i in range(0, n_win, 64)])  # <= 64 windows per call: one per work-group
+    np.testing.assert_array_equal(got, alone)
+    for i in rng.choice(n_win, 24, replace=False):
+        s0, l0 = int(starts[i]), int(lens[i])
+        sts = np.zeros((1, QL, S), np.float32); acs = np.zeros((1, QL, A), np.float32)
+        ts = np.zeros((1, QL), np.int64); am = np.zeros((1, QL), np.float32)
+        sts[0, QL - l0:] = obs[s0:s0 + l0]; acs[0, QL - l0:] = act[s0:s0 + l0]
+        ts[0, QL - l0:] = int(t0[i]) + np.arange(l0); am[0, QL - l0:] = 1
+        want = ro.pt_value_last(p, sts, acs, ts, am, num_heads=heads)[0]
+        np.testing.assert_allclose(got[i], want, rtol=5e-3, atol=5e-3)
+
+
 @pytest.mark.parametrize("correct", [False, True])
 def test_qlearning_dataset_pt_vs_oracle(g, correct):
     import iqlpref_amd as ia
