@@ -1049,8 +1049,23 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
       }
     }
     const bool mine = c2 / C::HQ == part;  // the part that owns this hidden unit stores its dZ2
+    bool lean = false;
+    if constexpr (BF16) lean = !drop_on;  // mask before the rounding (the same value), packed conversion
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
+      if (lean) {
+        if constexpr (BF16) {
+          float t[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t[i] = h2v[4 * g4 + i] > 0.f ? s[4 * g4 + i] : 0.f;
+          const uint2 u = make_uint2(pk_bf16(t[0], t[1]), pk_bf16(t[2], t[3]));
+          T *drow = dz2s + (4 * g4) * HP + c2;
+          drow[0] = (T)(u.x & 0xffff), drow[HP] = (T)(u.x >> 16);
+          drow[2 * HP] = (T)(u.y & 0xffff), drow[3 * HP] = (T)(u.y >> 16);
+          if (mine) stg8(dst + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), u);
+        }
+        continue;
+      }
       float outv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -1082,14 +1097,26 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
       P::mma(a, w2t[ks], acc);
     }
     const int col = 16 * tile0 + r;
-    float outv[4];
+    bool lean = false;
+    if constexpr (BF16) lean = !drop_on;
+    if (lean) {
+      if constexpr (BF16) {
+        float t[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float s = P::round(acc[i]);
-      if (drop_on) s = P::round(s * drop_scale);
-      outv[i] = h1v[i] > 0.f ? s : 0.f;
+        for (int i = 0; i < 4; ++i) t[i] = h1v[i] > 0.f ? acc[i] : 0.f;
+        stg8(g_dz1T + (size_t)net * H * BP + fidx<P>(col, slab * SLAB + 4 * q, nkb),
+             make_uint2(pk_bf16(t[0], t[1]), pk_bf16(t[2], t[3])));
+      }
+    } else {
+      float outv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float s = P::round(acc[i]);
+        if (drop_on) s = P::round(s * drop_scale);
+        outv[i] = h1v[i] > 0.f ? s : 0.f;
+      }
+      store4T<BF16>(g_dz1T + (size_t)net * H * BP + fidx<P>(col, slab * SLAB + 4 * q, nkb), outv);
     }
-    store4T<BF16>(g_dz1T + (size_t)net * H * BP + fidx<P>(col, slab * SLAB + 4 * q, nkb), outv);
   }
   STAMP(1, 4);
 }
