@@ -1678,12 +1678,10 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 // ------------------------------------------------------------------------
 // __global__ wrappers
 // ------------------------------------------------------------------------
-// WPE = waves per SIMD the register allocation must leave room for: 4 for one seed (what the code
-// needs: 112 VGPRs), 6 in group launches (thousands of short work-groups: more of them in flight)
-template <bool BF16, int H, int WPE>
-__global__ __launch_bounds__(256, WPE) void k_backward(const TrainerDesc *__restrict__ Dp,
-                                                       const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
-                                                       const int nslab, const int ntrain) {
+template <bool BF16, int H>
+__global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict__ Dp,
+                                                  const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
+                                                  const int nslab, const int ntrain) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   backward_body<BF16, H>(Dp + blockIdx.y, Cp + blockIdx.y, (int)blockIdx.x, smem, nslab, ntrain);
 }
@@ -1815,17 +1813,8 @@ hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *d
                            DevCtr *c, int n_seeds, hipStream_t st) {
   const int grid = 8 * ((layer2_parts(D.H) * D.ntrain + 7) / 8) * (D.B / SLAB);
   const size_t sm = bwd_smem_bytes(bf16, D.H);
-  static const int forced = getenv("IQLHIP_BWD_WPE") ? atoi(getenv("IQLHIP_BWD_WPE")) : 0;  // A/B knob
-  const int wpe = forced ? forced : (n_seeds >= 4 ? 6 : 4);
 #define CALL(BF, HH) \
-  do {                                                                                                              \
-    if (wpe >= 6 && BF)                                                                                             \
-      hipLaunchKernelGGL((k_backward<BF, HH, 6>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain); \
-    else if (wpe == 5 && BF)                                                                                        \
-      hipLaunchKernelGGL((k_backward<BF, HH, 5>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain); \
-    else                                                                                                            \
-      hipLaunchKernelGGL((k_backward<BF, HH, (BF ? 4 : 2)>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain); \
-  } while (0)
+  hipLaunchKernelGGL((k_backward<BF, HH>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain)
   DISPATCH_H(bf16, D.H, CALL);
 #undef CALL
   return hipGetLastError();
