@@ -434,8 +434,8 @@ struct FCfg {
   static_assert(HQ == 64, "one 16-column tile per wave and part");
 };
 
-template <bool BF16, int H, int MT, int PW>
-__global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__ Dp,
+template <bool BF16, int H, int MT, int PW, bool PRE>
+__global__ __launch_bounds__(256, PRE ? 1 : 3) void k_forward(const TrainerDesc *__restrict__ Dp,
                                                  const DevArgs *__restrict__ Ap,
                                                  const DevCtr *__restrict__ Cp, const int nsl_,
                                                  const int nfwd_) {
@@ -528,6 +528,29 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
   for (int jt = 0; jt < 2; ++jt)  // clamped (used for col < out_dim)
     bias3[jt] = ldg(N.b3 + (16 * jt + r < N.out_dim ? 16 * jt + r : N.out_dim - 1));
   uint4 w1[C::NK1][TPW], w2[PW][C::NK2], w3[PW][C::NK3][2];
+  // PRE (one seed: the shortest chain) requests the fragments of all three layers up front; the
+  // group variant requests layer 2 behind the layer-1 product and layer 3 behind the layer-2
+  // product: a third fewer live registers, three work-groups per CU instead of two, and the
+  // other work-groups cover the wait.
+  auto load_w2 = [&]() {
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const T *W2w = reinterpret_cast<const T *>(N.w2c) + (size_t)(tile2 + 4 * j) * C::NK2 * 64 * P::EPV;
+#pragma unroll
+      for (int ks = 0; ks < C::NK2; ++ks) w2[j][ks] = ldg16(W2w + ks * 64 * P::EPV + lane * P::EPV);
+    }
+  };
+  auto load_w3 = [&]() {
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const T *W3w = reinterpret_cast<const T *>(N.w3c) + (size_t)((part0 + j) * C::NK3) * 64 * P::EPV;
+#pragma unroll
+      for (int ks = 0; ks < C::NK3; ++ks)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+          if (jt < nt3) w3[j][ks][jt] = ldg16(W3w + (size_t)(jt * C::NK2 + ks) * 64 * P::EPV + lane * P::EPV);
+    }
+  };
   {
     // (scalar guard: a CU's L1 port moves 64 B / clk, a redundant 1 KiB fragment load costs the
     // work-group 16 cycles of it -- the load phase of this kernel is bound by exactly that)
@@ -540,21 +563,7 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
           w1[ks][jj] = ldg16(W1w + (size_t)(jj * nk1 + ks) * 64 * P::EPV + lane * P::EPV);
       }
     }
-#pragma unroll
-    for (int j = 0; j < PW; ++j) {
-      const T *W2w = reinterpret_cast<const T *>(N.w2c) + (size_t)(tile2 + 4 * j) * C::NK2 * 64 * P::EPV;
-#pragma unroll
-      for (int ks = 0; ks < C::NK2; ++ks) w2[j][ks] = ldg16(W2w + ks * 64 * P::EPV + lane * P::EPV);
-    }
-#pragma unroll
-    for (int j = 0; j < PW; ++j) {
-      const T *W3w = reinterpret_cast<const T *>(N.w3c) + (size_t)((part0 + j) * C::NK3) * 64 * P::EPV;
-#pragma unroll
-      for (int ks = 0; ks < C::NK3; ++ks)
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-          if (jt < nt3) w3[j][ks][jt] = ldg16(W3w + (size_t)(jt * C::NK2 + ks) * 64 * P::EPV + lane * P::EPV);
-    }
+    if constexpr (PRE) load_w2(), load_w3();
   }
   STAMP(0, 1);
 
@@ -599,6 +608,11 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
           for (int jj = 0; jj < TPW; ++jj) P::mma(a, w1[ks][jj], acc[m][jj]);
         }
       }
+    }
+    if constexpr (!PRE) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_w2();
+      __builtin_amdgcn_sched_barrier(0);
     }
     bool lean = false;
     if constexpr (BF16) lean = !N.dropout;  // (wave-uniform) see relu_bias_bf16x4
@@ -663,6 +677,11 @@ __global__ __launch_bounds__(256) void k_forward(const TrainerDesc *__restrict__
 #pragma unroll
         for (int j = 0; j < PW; ++j) P::mma(a, w2[j][ks], acc[j][m]);
       }
+    }
+    if constexpr (!PRE) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_w3();
+      __builtin_amdgcn_sched_barrier(0);
     }
     bool lean = false;
     if constexpr (BF16) lean = !N.dropout;
@@ -1785,11 +1804,18 @@ hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD
                           const DevCtr *c, int n_seeds, hipStream_t st) {
   const int mt = fwd_row_tiles(D.B, n_seeds), nsl = (D.B + 16 * mt - 1) / (16 * mt);
   const int pw = fwd_parts_per_wg(D.B, D.H, n_seeds);
+  static const int forced_pre = getenv("IQLHIP_FWD_PRE") ? atoi(getenv("IQLHIP_FWD_PRE")) : -1;  // A/B knob
+  const bool pre = forced_pre >= 0 ? forced_pre != 0 : (int64_t)D.B * n_seeds < 1024;
   // nfwd evaluations + the spare job, each nsl slabs x (SPL / pw) part groups
   const int grid = 8 * ((D.nfwd + 1 + 7) / 8) * nsl * (layer2_parts(D.H) / pw);
   const size_t sm = fwd_smem_bytes(bf16, D.H, D.k1max, mt, pw);
 #define LAUNCH_F(BF, HH, MTV, PWV)                                                                            \
-  hipLaunchKernelGGL((k_forward<BF, HH, MTV, PWV>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsl, D.nfwd)
+  do {                                                                                                        \
+    if (pre)                                                                                                  \
+      hipLaunchKernelGGL((k_forward<BF, HH, MTV, PWV, true>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsl, D.nfwd); \
+    else                                                                                                      \
+      hipLaunchKernelGGL((k_forward<BF, HH, MTV, PWV, false>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsl, D.nfwd); \
+  } while (0)
 #define CALL(BF, HH)                                                   \
   do {                                                                 \
     if constexpr (HH >= 128) {                                         \
