@@ -528,10 +528,11 @@ __global__ __launch_bounds__(256, PRE ? 1 : 3) void k_forward(const TrainerDesc 
   for (int jt = 0; jt < 2; ++jt)  // clamped (used for col < out_dim)
     bias3[jt] = ldg(N.b3 + (16 * jt + r < N.out_dim ? 16 * jt + r : N.out_dim - 1));
   uint4 w1[C::NK1][TPW], w2[PW][C::NK2], w3[PW][C::NK3][2];
-  // PRE (one seed: the shortest chain) requests the fragments of all three layers up front; the
-  // group variant requests layer 2 behind the layer-1 product and layer 3 behind the layer-2
-  // product: a third fewer live registers, three work-groups per CU instead of two, and the
-  // other work-groups cover the wait.
+  // PRE requests the fragments of all three layers up front (the shortest chain on paper); the
+  // default requests layer 2 behind the layer-1 product and layer 3 behind the layer-2 product:
+  // a third fewer live registers, three work-groups per CU instead of two, and the other
+  // work-groups cover the wait.  Measured faster everywhere: 63.7k vs 62.5k steps/s for one seed,
+  // 164.6k vs 157.3k for a group of 8 (IQLHIP_FWD_PRE=1 selects the old order).
   auto load_w2 = [&]() {
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
@@ -875,7 +876,7 @@ __device__ __forceinline__ void loss_terms(const TrainerDesc &D, int net, const 
 // The parts share the stores: part p writes its 64 columns of dZ2, part 0 writes dZ3 and the
 // loss partial sums.
 // ========================================================================
-template <bool BF16, int H>
+template <bool BF16, int H, bool PRE>
 __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp, DevCtr *__restrict__ Cp,
                                               const int blk, char *smem, const int nslab, const int ntrain) {
   using K = KCfg<BF16, H>;
@@ -970,14 +971,17 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
       load4T<BF16>(h2T + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), &h2v[4 * g4]);
   }
   __builtin_amdgcn_sched_barrier(0);
+  // PRE: the operands of the closing GEMM are requested here, ahead of everything; otherwise
+  // behind the dZ2 phase (fewer live registers, more work-groups per CU; A/B: IQLHIP_BWD_PRE)
   uint4 w2t[K::NK2];
-  {
+  float h1v[4];
+  auto load_gemm_operands = [&]() {
     const T *W2Tw = reinterpret_cast<const T *>(p_w2ct) + (size_t)tile0 * K::NK2 * 64 * P::EPV;
 #pragma unroll
     for (int ks = 0; ks < K::NK2; ++ks) w2t[ks] = ldg16(W2Tw + ks * 64 * P::EPV + lane * P::EPV);
-  }
-  float h1v[4];
-  load4T<BF16>(g_hT + (size_t)(net * 2 + 0) * H * BP + fidx<P>(16 * tile0 + r, slab * SLAB + 4 * q, nkb), h1v);
+    load4T<BF16>(g_hT + (size_t)(net * 2 + 0) * H * BP + fidx<P>(16 * tile0 + r, slab * SLAB + 4 * q, nkb), h1v);
+  };
+  if constexpr (PRE) load_gemm_operands();
   STAMP(1, 1);
 
   // ---- finish the forward outputs of this slab (sum of the parts, rounding, tanh) ----
@@ -1096,6 +1100,11 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
       }
       if (mine) store4T<BF16>(dst + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), outv);
     }
+  }
+  if constexpr (!PRE) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_gemm_operands();
+    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
   STAMP(1, 3);
@@ -1697,12 +1706,13 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 // ------------------------------------------------------------------------
 // __global__ wrappers
 // ------------------------------------------------------------------------
-template <bool BF16, int H>
-__global__ __launch_bounds__(256) void k_backward(const TrainerDesc *__restrict__ Dp,
-                                                  const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
-                                                  const int nslab, const int ntrain) {
+template <bool BF16, int H, bool PRE>
+__global__ __launch_bounds__(256, PRE ? 1 : (BF16 ? 6 : 3)) void k_backward(const TrainerDesc *__restrict__ Dp,
+                                                                            const DevArgs *__restrict__ Ap,
+                                                                            DevCtr *__restrict__ Cp, const int nslab,
+                                                                            const int ntrain) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  backward_body<BF16, H>(Dp + blockIdx.y, Cp + blockIdx.y, (int)blockIdx.x, smem, nslab, ntrain);
+  backward_body<BF16, H, PRE>(Dp + blockIdx.y, Cp + blockIdx.y, (int)blockIdx.x, smem, nslab, ntrain);
 }
 
 template <bool BF16, bool LAT>
@@ -1805,7 +1815,7 @@ hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD
   const int mt = fwd_row_tiles(D.B, n_seeds), nsl = (D.B + 16 * mt - 1) / (16 * mt);
   const int pw = fwd_parts_per_wg(D.B, D.H, n_seeds);
   static const int forced_pre = getenv("IQLHIP_FWD_PRE") ? atoi(getenv("IQLHIP_FWD_PRE")) : -1;  // A/B knob
-  const bool pre = forced_pre >= 0 ? forced_pre != 0 : (int64_t)D.B * n_seeds < 1024;
+  const bool pre = forced_pre > 0;  // measured: the just-in-time variant is faster for one seed as well (63.7k vs 62.5k)
   // nfwd evaluations + the spare job, each nsl slabs x (SPL / pw) part groups
   const int grid = 8 * ((D.nfwd + 1 + 7) / 8) * nsl * (layer2_parts(D.H) / pw);
   const size_t sm = fwd_smem_bytes(bf16, D.H, D.k1max, mt, pw);
@@ -1839,8 +1849,15 @@ hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *d
                            DevCtr *c, int n_seeds, hipStream_t st) {
   const int grid = 8 * ((layer2_parts(D.H) * D.ntrain + 7) / 8) * (D.B / SLAB);
   const size_t sm = bwd_smem_bytes(bf16, D.H);
-#define CALL(BF, HH) \
-  hipLaunchKernelGGL((k_backward<BF, HH>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain)
+  static const int forced_pre = getenv("IQLHIP_BWD_PRE") ? atoi(getenv("IQLHIP_BWD_PRE")) : -1;  // A/B knob
+  const bool pre = forced_pre >= 0 ? forced_pre != 0 : true;
+#define CALL(BF, HH)                                                                                                     \
+  do {                                                                                                                   \
+    if (pre)                                                                                                             \
+      hipLaunchKernelGGL((k_backward<BF, HH, true>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain);  \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((k_backward<BF, HH, false>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain); \
+  } while (0)
   DISPATCH_H(bf16, D.H, CALL);
 #undef CALL
   return hipGetLastError();
