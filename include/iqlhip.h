@@ -245,7 +245,7 @@ int iqlhip_group_train_steps(iqlhip_group *g, const iqlhip_replay_view *views, i
 /* A HIP stream confined to one slice of the compute units: CU i of the current device belongs
  * to slice i % n_slices (every slice spans all XCDs and memory channels).  Two seed groups
  * stepped on the two halves of the chip overlap one group's HBM-bound update with the other's
- * latency-bound forward / backward: 8 seeds as 2 x 4 measured 190k steps/s against 155k as one
+ * latency-bound forward / backward: 8 seeds as 2 x 4 measured 205k steps/s against 171k as one
  * group of 8 on the whole chip (tools/group_streams.py).  No counterpart in the reference (its
  * AGENTS_PER_GPU processes share the GPU unmanaged).  Destroy with iqlhip_stream_destroy.   */
 int iqlhip_stream_create_cu_slice(void **stream, int32_t slice, int32_t n_slices);

@@ -17,8 +17,8 @@ is bit-identical to running it alone.  Two execution modes:
     confined to its own slice of the compute units (CU i belongs to slice i % G,
     ``iqlhip_stream_create_cu_slice``).  The sub-groups never share a CU, only the memory system:
     one's HBM-bound k_update runs beside the other's latency-bound k_forward / k_backward.
-    Measured (tools/group_streams.py): 8 seeds as 2 x 4 190k steps/s against 155k as one group of
-    8; 16 seeds as 2 x 8 218k against 166k; 4 seeds as 2 x 2 143k against 119k.  Two slices are the
+    Measured (bench.py agents leg): 8 seeds as 2 x 4 205k steps/s against 171k as one group of 8;
+    4 seeds as 2 x 2 145k against 130k.  Two slices are the
     sweet spot (three do not divide the chip's 8 XCDs evenly, four leave each sub-group too few CUs).
 """
 import ctypes as C
