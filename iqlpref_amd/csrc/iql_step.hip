@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256, PRE ? 1 : 3) void k_forward(const TrainerDesc 
   // default requests layer 2 behind the layer-1 product and layer 3 behind the layer-2 product:
   // a third fewer live registers, three work-groups per CU instead of two, and the other
   // work-groups cover the wait.  Measured faster everywhere: 63.7k vs 62.5k steps/s for one seed,
-  // 164.6k vs 157.3k for a group of 8 (IQLHIP_FWD_PRE=1 selects the old order).
+  // 164.6k vs 157.3k for a group of 8; only the just-in-time order is instantiated.
   auto load_w2 = [&]() {
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
@@ -1782,7 +1782,7 @@ size_t bwd_smem_bytes(bool bf16, int H) {
 // work-group (K = 8: 154.8k steps/s against 150.2k with 64 rows x one part, 139.7k with 32 x one).
 int fwd_row_tiles(int B, int n_seeds) {
   static const int forced = getenv("IQLHIP_FWD_MT") ? atoi(getenv("IQLHIP_FWD_MT")) : 0;  // A/B knob
-  if ((forced == 1 || forced == 2 || forced == 4) && B % (16 * forced) == 0) return forced;
+  if ((forced == 1 || forced == 2) && B % (16 * forced) == 0) return forced;
   const int64_t rows = (int64_t)B * n_seeds;
   if (rows >= 512 && B % 32 == 0) return 2;
   return 1;
@@ -1814,30 +1814,21 @@ hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD
                           const DevCtr *c, int n_seeds, hipStream_t st) {
   const int mt = fwd_row_tiles(D.B, n_seeds), nsl = (D.B + 16 * mt - 1) / (16 * mt);
   const int pw = fwd_parts_per_wg(D.B, D.H, n_seeds);
-  static const int forced_pre = getenv("IQLHIP_FWD_PRE") ? atoi(getenv("IQLHIP_FWD_PRE")) : -1;  // A/B knob
-  const bool pre = forced_pre > 0;  // measured: the just-in-time variant is faster for one seed as well (63.7k vs 62.5k)
   // nfwd evaluations + the spare job, each nsl slabs x (SPL / pw) part groups
   const int grid = 8 * ((D.nfwd + 1 + 7) / 8) * nsl * (layer2_parts(D.H) / pw);
   const size_t sm = fwd_smem_bytes(bf16, D.H, D.k1max, mt, pw);
 #define LAUNCH_F(BF, HH, MTV, PWV)                                                                            \
-  do {                                                                                                        \
-    if (pre)                                                                                                  \
-      hipLaunchKernelGGL((k_forward<BF, HH, MTV, PWV, true>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsl, D.nfwd); \
-    else                                                                                                      \
-      hipLaunchKernelGGL((k_forward<BF, HH, MTV, PWV, false>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsl, D.nfwd); \
-  } while (0)
+  hipLaunchKernelGGL((k_forward<BF, HH, MTV, PWV, false>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsl, D.nfwd)
 #define CALL(BF, HH)                                                   \
   do {                                                                 \
     if constexpr (HH >= 128) {                                         \
       if (pw == 2) {                                                   \
-        if (mt == 4) LAUNCH_F(BF, HH, 4, 2);                           \
-        else if (mt == 2) LAUNCH_F(BF, HH, 2, 2);                      \
+        if (mt == 2) LAUNCH_F(BF, HH, 2, 2);                           \
         else LAUNCH_F(BF, HH, 1, 2);                                   \
         break;                                                         \
       }                                                                \
     }                                                                  \
-    if (mt == 4) LAUNCH_F(BF, HH, 4, 1);                               \
-    else if (mt == 2) LAUNCH_F(BF, HH, 2, 1);                          \
+    if (mt == 2) LAUNCH_F(BF, HH, 2, 1);                               \
     else LAUNCH_F(BF, HH, 1, 1);                                       \
   } while (0)
   DISPATCH_H(bf16, D.H, CALL);
