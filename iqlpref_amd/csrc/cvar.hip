@@ -23,6 +23,23 @@ __device__ __forceinline__ float key2f(uint32_t k) {
   return __builtin_bit_cast(float, u);
 }
 
+// minimum over aligned groups of W consecutive lanes (W a power of two <= 32), result in every lane
+template <int W>
+__device__ __forceinline__ uint32_t lane_min_u32(uint32_t v) {
+  if constexpr (W >= 2) v = min(v, dpp_mov<0xB1>(v));
+  if constexpr (W >= 4) v = min(v, dpp_mov<0x4E>(v));
+  if constexpr (W >= 8) v = min(v, dpp_mov<0x141>(v));
+  if constexpr (W >= 16) v = min(v, dpp_mov<0x140>(v));
+  if constexpr (W >= 32) {
+    uint32_t a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    v = min(a, b);
+  }
+  return v;
+}
+
+constexpr int SMALL_TAIL = 8;  // up to this many tail elements are taken one distinct minimum at a time
+
 // COLS columns per work-group, L consecutive lanes per column (COLS * L threads)
 template <int COLS, int L>
 __global__ __launch_bounds__(COLS *L) void k_cvar(const float *__restrict__ preds, int S, int64_t N,
@@ -41,6 +58,37 @@ __global__ __launch_bounds__(COLS *L) void k_cvar(const float *__restrict__ pred
   const int c = tid / L, p = tid % L;
   const uint32_t *col = keys + c * SP;
   const int S4 = round_up(S, 4);  // (keys beyond S compare greater than every threshold below 2^32 - 1)
+  if (n_tail <= SMALL_TAIL) {
+    // ---- short tails (n_tail = 1 is the snapshot ensemble of ref:1152 at S = 20: the minimum):
+    // at most n_tail passes, each taking the next distinct minimum with its multiplicity --
+    // n_tail x S compares instead of the 32 x S of the bisection below ----
+    uint32_t prev = 0u;
+    int taken = 0;
+    float sum = 0.f;
+#pragma unroll 1
+    for (int it = 0; it < n_tail; ++it) {
+      uint32_t lm = 0xffffffffu;
+      int lc = 0;
+      for (int k = 4 * p; k < S4; k += 4 * L) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(col + k);
+        const uint32_t kk[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (it == 0 || kk[e] > prev) {
+            lc = kk[e] < lm ? 1 : (kk[e] == lm ? lc + 1 : lc);
+            lm = min(lm, kk[e]);
+          }
+        }
+      }
+      const uint32_t gm = lane_min_u32<L>(lm);
+      const int gc = lane_sum<L>(lm == gm ? lc : 0);
+      const int take = min(gc, n_tail - taken);  // 0 once the tail is complete
+      if (take > 0) sum += (float)take * key2f(gm);
+      taken += take, prev = gm;
+    }
+    if (p == 0 && col0 + c < N) out[col0 + c] = sum / (float)n_tail;
+    return;
+  }
   // smallest key t such that #(keys <= t) >= n_tail  == the n_tail-th smallest key
   uint32_t lo = 0u, hi = 0xffffffffu;
 #pragma unroll 1

@@ -79,6 +79,8 @@ def test_cvar_kernel_vs_partition():
         preds[:, : N // 3] = np.round(preds[:, : N // 3], 1)  # ties
         if S > 2:
             preds[1, 0] = preds[0, 0]
+        preds[:, N - 1] = 0.25           # one column of S equal values
+        preds[: S // 2, N - 2] = -3.0     # and one whose smaller half is one value
         for alpha in (0.0, 0.5, 0.9, 0.95):
             n_tail = ro.n_tail_of(alpha, S)
             got = cvar_tail_mean_device(torch.from_numpy(preds).to(DEV), n_tail).cpu().numpy()
