@@ -435,7 +435,7 @@ struct FCfg {
 };
 
 template <bool BF16, int H, int MT, int PW, bool PRE>
-__global__ __launch_bounds__(256, PRE ? 1 : 4) void k_forward(const TrainerDesc *__restrict__ Dp,
+__global__ __launch_bounds__(256, PRE ? 1 : 3) void k_forward(const TrainerDesc *__restrict__ Dp,
                                                  const DevArgs *__restrict__ Ap,
                                                  const DevCtr *__restrict__ Cp, const int nsl_,
                                                  const int nfwd_) {
