@@ -51,26 +51,6 @@ __device__ __forceinline__ uint2 ldg8(const void *p) {
 __device__ __forceinline__ void stg16(void *p, float4 v) {
   *(u32x4_t IQL_AS1 *)p = __builtin_bit_cast(u32x4_t, v);
 }
-// streaming variants for data nobody reads again before the next launch of the same kernel (the
-// optimiser state): `nt` marks the lines for early eviction, so less of it is still dirty in the
-// XCD's L2 when the kernel ends and the release at the boundary has less to write back
-#ifdef IQL_NT_STATE
-template <class T>
-__device__ __forceinline__ void stg_s(T *p, T v) {
-  __builtin_nontemporal_store(v, (T IQL_AS1 *)p);
-}
-__device__ __forceinline__ void stg16_s(void *p, float4 v) {
-  __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), (u32x4_t IQL_AS1 *)p);
-}
-#else
-template <class T>
-__device__ __forceinline__ void stg_s(T *p, T v) {
-  *(T IQL_AS1 *)p = v;
-}
-__device__ __forceinline__ void stg16_s(void *p, float4 v) {
-  *(u32x4_t IQL_AS1 *)p = __builtin_bit_cast(u32x4_t, v);
-}
-#endif
 __device__ __forceinline__ void stg8(void *p, uint2 v) {
   *(u32x2_t IQL_AS1 *)p = __builtin_bit_cast(u32x2_t, v);
 }

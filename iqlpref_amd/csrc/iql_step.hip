@@ -1472,12 +1472,12 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
         float p_ = pf[k], m_ = mf[k], v_ = vf[k];
         adam_apply(p_, m_, v_, g, coef, neg_step);
         tile[ol * TLD + i] = p_;
-        stg_s(g_params + fbase + e, p_), stg_s(g_m + fbase + e, m_), stg_s(g_v + fbase + e, v_);
+        stg(g_params + fbase + e, p_), stg(g_m + fbase + e, m_), stg(g_v + fbase + e, v_);
         if (g_grads) stg(g_grads + fbase + e, g);
         if (has_target) {
           const float t_ = polyak(D, tf[k], p_);
           tile2[ol * TLD + i] = t_;
-          stg_s(g_target + tbase + e, t_);
+          stg(g_target + tbase + e, t_);
         }
       }
     }
@@ -1660,11 +1660,11 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     if (o < Odim && i < Idim) {
       const int64_t e = it.off_w + (int64_t)o * Idim + i;
       const int64_t te = it.toff_w + (int64_t)o * Idim + i;
-      stg16_s(g_params + e, make_float4(p[0], p[1], p[2], p[3]));
-      stg16_s(g_m + e, make_float4(m[0], m[1], m[2], m[3]));
-      stg16_s(g_v + e, make_float4(v[0], v[1], v[2], v[3]));
+      stg16(g_params + e, make_float4(p[0], p[1], p[2], p[3]));
+      stg16(g_m + e, make_float4(m[0], m[1], m[2], m[3]));
+      stg16(g_v + e, make_float4(v[0], v[1], v[2], v[3]));
       if (g_grads) stg16(g_grads + e, make_float4(g[0], g[1], g[2], g[3]));
-      if (has_target) stg16_s(g_target + te, make_float4(tv[0], tv[1], tv[2], tv[3]));
+      if (has_target) stg16(g_target + te, make_float4(tv[0], tv[1], tv[2], tv[3]));
       // 4 consecutive k of one row are contiguous in the fragment-major copies
       store4T<BF16>(wc + fidx<P>(o, i, nkw), p);
       if (has_target) store4T<BF16>(tc + fidx<P>(o, i, nkw), tv);
