@@ -16,23 +16,25 @@ buf = ia.ReplayBuffer(bench.S_DIM, bench.A_DIM, 200_000, dev)
 buf.load_d4rl_dataset(bench.synth_dataset(1, 200_000))
 tr = bench.build_trainer(ia, torch, dev, 1, "bf16")
 K = 20
-tr.train_steps(buf, 200, bench.BATCH, return_losses=False, graph_unroll=K)
-torch.cuda.synchronize()
 pc = time.perf_counter
-host, block, sync_idle = [], [], []
-for _ in range(2000):
-    torch.cuda.synchronize()
-    t0 = pc()
-    tr.train_steps(buf, K, bench.BATCH, return_losses=False, graph_unroll=K)
-    t1 = pc()
-    torch.cuda.synchronize()
-    t2 = pc()
-    host.append(t1 - t0), block.append(t2 - t0)
-    t3 = pc()
-    torch.cuda.synchronize()
-    sync_idle.append(pc() - t3)
 med = lambda x: sorted(x)[len(x) // 2] * 1e6
-print(f"train_steps host time {med(host):.1f} us; block {med(block):.1f} us; idle synchronize {med(sync_idle):.1f} us")
+for unroll in (K, 10, 5, 0):  # one graph of K steps, shorter graphs, eager launches
+    tr.train_steps(buf, 200, bench.BATCH, return_losses=False, graph_unroll=unroll)
+    torch.cuda.synchronize()
+    host, block, sync_idle = [], [], []
+    for _ in range(1500):
+        torch.cuda.synchronize()
+        t0 = pc()
+        tr.train_steps(buf, K, bench.BATCH, return_losses=False, graph_unroll=unroll)
+        t1 = pc()
+        torch.cuda.synchronize()
+        t2 = pc()
+        host.append(t1 - t0), block.append(t2 - t0)
+        t3 = pc()
+        torch.cuda.synchronize()
+        sync_idle.append(pc() - t3)
+    print(f"unroll {unroll:2d}: train_steps host time {med(host):.1f} us; block {med(block):.1f} us "
+          f"({K / med(block) * 1e6:.0f} steps/s); idle synchronize {med(sync_idle):.1f} us", flush=True)
 # pieces of the host time
 import ctypes as C
 from iqlpref_amd import _lib
