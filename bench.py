@@ -316,7 +316,7 @@ def main():
             "config": {"workload": "IQL antmaze-medium-diverse-v2 shapes (S=29 A=8 H=256), "
                                    "1M-transition device replay, batch 256, one seed per GPU",
                        "batch": BATCH, "buffer_rows": N_ROWS, "graph_unroll": unroll,
-                       "graphs_per_call": graph_plan(min(K, chunk), unroll), "steps_per_call": min(K, chunk)},
+                       "graph_launches_per_block": K // unroll, "eager_steps_per_block": K % unroll},
             "timing": {"reps": reps, "timed_steps_total": reps * K,
                        "block_ms": {"median": dt_med * 1e3, "min": float(blk[0]) * 1e3,
                                     "max": float(blk[-1]) * 1e3},
@@ -381,26 +381,6 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def graph_plan(n, unroll):
-    """Steps per hipGraph of one n-step call, as the library replays them (api.hip replay_steps): a
-    2-step ramp graph (the GPU starts while the host still submits the long one), graphs of `unroll`
-    steps, one graph of the rest; fewer than 4 left-over steps run as plain launches."""
-    if unroll <= 0 or n < unroll:
-        return {"graphs": [], "eager_steps": n}
-    plan, rem = [], n
-    if rem >= 8 and unroll > 2:
-        plan.append(2)
-        rem -= 2
-    plan += [unroll] * (rem // unroll)
-    rem %= unroll
-    if rem >= 4:
-        plan.append(rem)
-        rem = 0
-    if len(plan) > 6:
-        plan = plan[:2] + ["... x%d" % (len(plan) - 3)] + plan[-1:]
-    return {"graphs": plan, "eager_steps": rem}
 
 
 def agents_leg(ia, torch, tr, buf, device, seed, args, unroll, bytes_step):

@@ -95,92 +95,6 @@ static hipError_t capture_stream(hipStream_t *out) {
   return hipSuccess;
 }
 
-// hipGraphs of whole steps, by step count.  A call's steps are replayed as a SHORT graph first
-// (GRAPH_RAMP steps: its launch costs the host a few microseconds, so the GPU starts at once), then
-// graphs of `graph_unroll` steps, then one graph of what is left; launching the long graph costs
-// ~0.5 us per kernel node before its first kernel runs (26 us of a 0.34 ms block of 20 steps).
-constexpr int GRAPH_RAMP = 2;
-constexpr int GRAPH_SLOTS = 4;
-struct GraphCache {
-  hipGraphExec_t exec[GRAPH_SLOTS] = {};
-  int steps[GRAPH_SLOTS] = {};
-  unsigned age[GRAPH_SLOTS] = {};
-  unsigned clock = 0;
-  void clear() {
-    for (int i = 0; i < GRAPH_SLOTS; ++i) {
-      if (exec[i]) (void)hipGraphExecDestroy(exec[i]);
-      exec[i] = nullptr, steps[i] = 0, age[i] = 0;
-    }
-  }
-  hipGraphExec_t find(int n) {
-    for (int i = 0; i < GRAPH_SLOTS; ++i)
-      if (exec[i] && steps[i] == n) {
-        age[i] = ++clock;
-        return exec[i];
-      }
-    return nullptr;
-  }
-  void put(int n, hipGraphExec_t e) {  // replaces the least recently used slot
-    int v = 0;
-    for (int i = 0; i < GRAPH_SLOTS; ++i) {
-      if (!exec[i]) {
-        v = i;
-        break;
-      }
-      if (age[i] < age[v]) v = i;
-    }
-    if (exec[v]) (void)hipGraphExecDestroy(exec[v]);
-    exec[v] = e, steps[v] = n, age[v] = ++clock;
-  }
-};
-// capture `n` steps (enqueue(stream) enqueues one step) on the capture stream and instantiate
-template <class Enqueue>
-static int capture_steps(GraphCache &gc, int n, hipStream_t cap, Enqueue enqueue, hipGraphExec_t *out) {
-  if (hipGraphExec_t e = gc.find(n)) {
-    *out = e;
-    return 0;
-  }
-  hipGraph_t g = nullptr;
-  HIP_TRY(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-  int rc = 0;
-  for (int u = 0; u < n && !rc; ++u) rc = enqueue(cap);
-  hipError_t ce = hipStreamEndCapture(cap, &g);
-  if (rc) return rc;
-  HIP_TRY(ce);
-  hipGraphExec_t e = nullptr;
-  HIP_TRY(hipGraphInstantiate(&e, g, nullptr, nullptr, 0));
-  (void)hipGraphDestroy(g);
-  gc.put(n, e);
-  *out = e;
-  return 0;
-}
-// the steps of a call: ramp graph, full graphs, tail graph, the last few eagerly
-template <class Enqueue>
-static int replay_steps(GraphCache &gc, int64_t n_steps, int graph_unroll, hipStream_t cap, hipStream_t st,
-                        Enqueue enqueue) {
-  int64_t rem = n_steps;
-  if (graph_unroll > 0 && n_steps >= graph_unroll) {
-    hipGraphExec_t e = nullptr;
-    if (rem >= 4 * GRAPH_RAMP && graph_unroll > GRAPH_RAMP) {
-      if (int rc = capture_steps(gc, GRAPH_RAMP, cap, enqueue, &e)) return rc;
-      HIP_TRY(hipGraphLaunch(e, st));
-      rem -= GRAPH_RAMP;
-    }
-    if (rem >= graph_unroll) {
-      if (int rc = capture_steps(gc, graph_unroll, cap, enqueue, &e)) return rc;
-      for (; rem >= graph_unroll; rem -= graph_unroll) HIP_TRY(hipGraphLaunch(e, st));
-    }
-    if (rem >= 4) {
-      if (int rc = capture_steps(gc, (int)rem, cap, enqueue, &e)) return rc;
-      HIP_TRY(hipGraphLaunch(e, st));
-      rem = 0;
-    }
-  }
-  for (; rem > 0; --rem)
-    if (int rc = enqueue(st)) return rc;
-  return 0;
-}
-
 extern "C" int iqlhip_abi_version(void) { return 4; }
 // sha256 prefix of csrc/* + include/iqlhip.h, stamped by iqlpref_amd/build.py: the Python side
 // refuses a library whose tag does not match the sources it sits beside
@@ -314,7 +228,9 @@ struct iqlhip_trainer {
 
   int64_t total_it = 0;
   double lr_q, lr_v, lr_a_base;
-  GraphCache graphs;  // hipGraphs of whole steps (replay_steps)
+  // hipGraph of `graph_unroll` steps
+  hipGraphExec_t gexec = nullptr;
+  int graph_unroll = 0;
   hipStream_t cap_stream = nullptr;  // capture only (the legacy default stream cannot capture); shared, see capture_stream
   // timing
   bool timing = false;
@@ -672,7 +588,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
 extern "C" int iqlhip_trainer_destroy(iqlhip_trainer *t) {
   if (!t) return 0;
   if (t->group) return fail(IQLHIP_ERR_INVALID, "trainer is a member of a group: destroy the group first");
-  t->graphs.clear();
+  if (t->gexec) (void)hipGraphExecDestroy(t->gexec);
   for (int k = 0; k < iqlhip_trainer::ARG_RING; ++k) {
     if (t->harg_ev[k]) (void)hipEventDestroy(t->harg_ev[k]);
     if (t->harg[k]) (void)hipHostFree(t->harg[k]);
@@ -822,9 +738,29 @@ static int run_steps(iqlhip_trainer *t, const DevArgs &args_in, int64_t n_steps,
     }
     return 0;
   }
-  if (graph_unroll > 0 && n_steps >= graph_unroll && !t->cap_stream) HIP_TRY(capture_stream(&t->cap_stream));
-  return replay_steps(t->graphs, n_steps - done, graph_unroll, t->cap_stream, st,
-                      [t](hipStream_t s_) { return enqueue_step(t, s_); });
+  if (graph_unroll > 0 && n_steps >= graph_unroll) {
+    if (!t->gexec || t->graph_unroll != graph_unroll) {
+      if (t->gexec) {
+        (void)hipGraphExecDestroy(t->gexec);
+        t->gexec = nullptr;
+      }
+      hipGraph_t g = nullptr;
+      if (!t->cap_stream) HIP_TRY(capture_stream(&t->cap_stream));
+      HIP_TRY(hipStreamBeginCapture(t->cap_stream, hipStreamCaptureModeThreadLocal));
+      int rc = 0;
+      for (int u = 0; u < graph_unroll && !rc; ++u) rc = enqueue_step(t, t->cap_stream);
+      hipError_t ce = hipStreamEndCapture(t->cap_stream, &g);
+      if (rc) return rc;
+      HIP_TRY(ce);
+      HIP_TRY(hipGraphInstantiate(&t->gexec, g, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(g);
+      t->graph_unroll = graph_unroll;
+    }
+    for (; done + graph_unroll <= n_steps; done += graph_unroll) HIP_TRY(hipGraphLaunch(t->gexec, st));
+  }
+  for (; done < n_steps; ++done)
+    if (int rc = enqueue_step(t, st)) return rc;
+  return 0;
 }
 
 extern "C" int iqlhip_train_steps(iqlhip_trainer *t, const iqlhip_replay_view *view, int64_t n_steps,
@@ -892,7 +828,8 @@ struct iqlhip_group {
   hipEvent_t harg_ev[ARG_RING] = {};
   bool harg_used[ARG_RING] = {};
   int harg_head = 0;
-  GraphCache graphs;
+  hipGraphExec_t gexec = nullptr;
+  int graph_unroll = 0;
   hipStream_t cap_stream = nullptr;
   DevArgs dev_args[IQLHIP_MAX_GROUP];  // what the device copies hold (see `continues`)
   bool dev_args_valid = false;
@@ -959,7 +896,10 @@ extern "C" int iqlhip_group_create(iqlhip_group **out, iqlhip_trainer *const *tr
     g->tr[k] = t;
     t->group = g;
     t->ddesc = g->gdesc + k, t->dargs = g->gargs + k, t->dctr = g->gctr + k, t->ditems = g->gitems + (size_t)k * ni;
-    t->graphs.clear();  // the member's own graphs hold the old descriptor addresses
+    if (t->gexec) {  // the member's own graph holds the old descriptor addresses
+      (void)hipGraphExecDestroy(t->gexec);
+      t->gexec = nullptr;
+    }
   }
   *out = g;
   return 0;
@@ -975,9 +915,12 @@ extern "C" int iqlhip_group_destroy(iqlhip_group *g) {
     (void)hipMemcpy(t->own_dctr, t->dctr, sizeof(DevCtr), hipMemcpyDeviceToDevice);
     t->ddesc = t->own_ddesc, t->dargs = t->own_dargs, t->dctr = t->own_dctr, t->ditems = t->own_ditems;
     t->group = nullptr;
-    t->graphs.clear();
+    if (t->gexec) {
+      (void)hipGraphExecDestroy(t->gexec);
+      t->gexec = nullptr;
+    }
   }
-  g->graphs.clear();
+  if (g->gexec) (void)hipGraphExecDestroy(g->gexec);
   for (auto &e : g->ev)
     if (e) (void)hipEventDestroy(e);
   for (int k = 0; k < iqlhip_group::ARG_RING; ++k) {
@@ -1081,10 +1024,28 @@ extern "C" int iqlhip_group_train_steps(iqlhip_group *g, const iqlhip_replay_vie
     for (int k = 0; k < g->K; ++k) g->tr[k]->total_it += n_steps;
     return 0;
   }
-  if (graph_unroll > 0 && n_steps >= graph_unroll && !g->cap_stream) HIP_TRY(capture_stream(&g->cap_stream));
-  if (int rc = replay_steps(g->graphs, n_steps - done, graph_unroll, g->cap_stream, st,
-                            [g](hipStream_t s_) { return group_enqueue_step(g, s_); }))
-    return rc;
+  if (graph_unroll > 0 && n_steps >= graph_unroll) {
+    if (!g->gexec || g->graph_unroll != graph_unroll) {
+      if (g->gexec) {
+        (void)hipGraphExecDestroy(g->gexec);
+        g->gexec = nullptr;
+      }
+      hipGraph_t gr = nullptr;
+      if (!g->cap_stream) HIP_TRY(capture_stream(&g->cap_stream));
+      HIP_TRY(hipStreamBeginCapture(g->cap_stream, hipStreamCaptureModeThreadLocal));
+      int rc = 0;
+      for (int u = 0; u < graph_unroll && !rc; ++u) rc = group_enqueue_step(g, g->cap_stream);
+      hipError_t ce = hipStreamEndCapture(g->cap_stream, &gr);
+      if (rc) return rc;
+      HIP_TRY(ce);
+      HIP_TRY(hipGraphInstantiate(&g->gexec, gr, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(gr);
+      g->graph_unroll = graph_unroll;
+    }
+    for (; done + graph_unroll <= n_steps; done += graph_unroll) HIP_TRY(hipGraphLaunch(g->gexec, st));
+  }
+  for (; done < n_steps; ++done)
+    if (int rc = group_enqueue_step(g, st)) return rc;
   for (int k = 0; k < g->K; ++k) g->tr[k]->total_it += n_steps;
   return 0;
 }
@@ -1187,7 +1148,10 @@ extern "C" int iqlhip_trainer_set_debug(iqlhip_trainer *t, void *buf) {
   if (!t) return fail(IQLHIP_ERR_INVALID, "null trainer");
   t->D.dbg = reinterpret_cast<unsigned long long *>(buf);
   HIP_TRY(hipMemcpy(t->ddesc, &t->D, sizeof(TrainerDesc), hipMemcpyHostToDevice));
-  t->graphs.clear();
+  if (t->gexec) {
+    (void)hipGraphExecDestroy(t->gexec);
+    t->gexec = nullptr;
+  }
   return 0;
 }
 
