@@ -416,6 +416,33 @@ def test_seed_group_matches_separate_runs(gh, mode):
     np.testing.assert_array_equal(solo, alone[1].train_steps(buf, 5, B, graph_unroll=2).cpu().numpy())
 
 
+def test_seed_group_split_uneven_and_cu_slice_streams(gh):
+    """mode="split" with three seeds (sub-groups of two and one) on the CU-slice streams, driven
+    with per-seed injected indices: bit-identical to the seeds alone.  The C entry point refuses
+    slices that do not exist."""
+    import ctypes as C
+    import iqlpref_amd as ia
+    from iqlpref_amd import _lib
+    d, hyper, data, nets = helpers.load_traj("traj_antmaze", "bf16")
+    B = hyper["batch"]
+    buf = gh.make_buffer(hyper, data)
+    seeds = (11, 12, 13)
+    alone = [gh.make_trainer(hyper, nets, "bf16", seed=s) for s in seeds]
+    want = [t.train_steps(buf, 21, B, graph_unroll=5).cpu().numpy() for t in alone]
+    group = ia.SeedGroup([gh.make_trainer(hyper, nets, "bf16", seed=s) for s in seeds], chunk=8, mode="split")
+    assert [len(ch) for ch in group._children] == [2, 1]
+    got = group.train_steps(buf, 21, B, return_losses=True, graph_unroll=5)
+    group.synchronize()
+    for w, g_ in zip(want, got):
+        np.testing.assert_array_equal(w, g_.cpu().numpy())
+    group.close()
+    lib = _lib.load()
+    st = C.c_void_p()
+    for sl, n in ((2, 2), (-1, 2), (0, 0), (0, 100000)):
+        assert lib.iqlhip_stream_create_cu_slice(C.byref(st), sl, n) != 0
+    assert lib.iqlhip_stream_create_cu_slice(None, 0, 2) != 0
+
+
 def test_seed_group_injected_indices_and_own_buffers(gh):
     """Group launch with per-seed replay buffers, injected indices and dropout masks (the parity
     inputs of the golden trajectories): every member reproduces its solo trajectory bit for bit."""
