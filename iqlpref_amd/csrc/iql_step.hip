@@ -876,7 +876,7 @@ __device__ __forceinline__ void loss_terms(const TrainerDesc &D, int net, const 
 // The parts share the stores: part p writes its 64 columns of dZ2, part 0 writes dZ3 and the
 // loss partial sums.
 // ========================================================================
-template <bool BF16, int H, bool PRE, int MT>
+template <bool BF16, int H, bool PRE>
 __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp, DevCtr *__restrict__ Cp,
                                               const int blk, char *smem, const int nslab, const int ntrain) {
   using K = KCfg<BF16, H>;
@@ -888,8 +888,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   // W2^T its work-groups stream).  (nslab, ntrain: preloaded kernel arguments, see k_forward)
   const TrainerDesc &D = *Dp;
   const int idx_ = blk >> 3;
-  // (nslab counts this launch's slab GROUPS: MT consecutive 16-row slabs per work-group)
-  const int job = (idx_ / nslab) * 8 + (blk & 7), sgrp = idx_ % nslab;
+  const int job = (idx_ / nslab) * 8 + (blk & 7), slab = idx_ % nslab;
   const int net = job / SPL;
   const int part = __builtin_amdgcn_readfirstlane(job % SPL);
   if (net >= ntrain) return;
@@ -925,21 +924,9 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   if (blk == 0 && tid == 0) Cp->ctr[1] = Cp->ctr[0] + 1;
   STAMP(1, 0);
 
-  const int lrow = tid >> 4, lj = tid & 15;
-  const int c2 = tid < H ? tid : H - 1;  // hidden unit this thread owns in the dZ2 phase
-  // W3^T [H][out_pad]: this unit's weights to every output, 8 (bf16) / 4 (fp32) per 16-byte load
-  constexpr int W3G = 32 / P::EPV;  // 16-byte groups covering 32 outputs
-  uint4 w3q[W3G];
-  uint4 w2t[K::NK2];
-  // MT slabs one after the other (group launches: MT = 2): the scalar prologue above and the
-  // weights (w3q, w2t) are paid once per work-group; the LDS buffers are reused behind the
-  // barriers of the next slab (every reader of a buffer is at least one barrier ahead of its
-  // next writer).
-#pragma unroll 1
-  for (int ms = 0; ms < MT; ++ms) {
-  const int slab = sgrp * MT + ms;
   // ---- the loss inputs first: loads return in order, these must not queue behind the
   // weight stream requested next.  Thread (row tid / 16, lane16 = tid % 16). ----
+  const int lrow = tid >> 4, lj = tid & 15;
   const int brow = slab * SLAB + lrow;
   float pv[FIN_NC][SPL];
   {
@@ -966,7 +953,11 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   // ---- request everything else that does not depend on the loss, in the order it is
   // consumed: W3 and h2 for the dZ2 phase, then this part of W2^T for the GEMM, h1 for its
   // epilogue.  All unconditional (clamped). ----
-  if (ms == 0) {
+  const int c2 = tid < H ? tid : H - 1;  // hidden unit this thread owns in the dZ2 phase
+  // W3^T [H][out_pad]: this unit's weights to every output, 8 (bf16) / 4 (fp32) per 16-byte load
+  constexpr int W3G = 32 / P::EPV;  // 16-byte groups covering 32 outputs
+  uint4 w3q[W3G];
+  {
     const T *w3row = reinterpret_cast<const T *>(p_w3t) + (size_t)c2 * out_pad;
 #pragma unroll
     for (int g = 0; g < W3G; ++g)
@@ -982,13 +973,12 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   __builtin_amdgcn_sched_barrier(0);
   // PRE: the operands of the closing GEMM are requested here, ahead of everything; otherwise
   // behind the dZ2 phase (fewer live registers, more work-groups per CU; A/B: IQLHIP_BWD_PRE)
+  uint4 w2t[K::NK2];
   float h1v[4];
   auto load_gemm_operands = [&]() {
-    if (ms == 0) {
-      const T *W2Tw = reinterpret_cast<const T *>(p_w2ct) + (size_t)tile0 * K::NK2 * 64 * P::EPV;
+    const T *W2Tw = reinterpret_cast<const T *>(p_w2ct) + (size_t)tile0 * K::NK2 * 64 * P::EPV;
 #pragma unroll
-      for (int ks = 0; ks < K::NK2; ++ks) w2t[ks] = ldg16(W2Tw + ks * 64 * P::EPV + lane * P::EPV);
-    }
+    for (int ks = 0; ks < K::NK2; ++ks) w2t[ks] = ldg16(W2Tw + ks * 64 * P::EPV + lane * P::EPV);
     load4T<BF16>(g_hT + (size_t)(net * 2 + 0) * H * BP + fidx<P>(16 * tile0 + r, slab * SLAB + 4 * q, nkb), h1v);
   };
   if constexpr (PRE) load_gemm_operands();
@@ -1122,7 +1112,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     float s = 0.f;
 #pragma unroll
     for (int rr = 0; rr < SLAB; ++rr) s += rowsum[rr];
-    stg(g_lossp + net * (nslab * MT) + slab, s);
+    stg(g_lossp + net * nslab + slab, s);
   }
 
   // ---- dZ1 = (dZ2 W2) * relu'(h1)   (MFMA, B operand = transposed copy; one n-tile per wave) ----
@@ -1157,7 +1147,6 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     }
   }
   STAMP(1, 4);
-  }  // slabs of this work-group
 }
 
 // ========================================================================
@@ -1717,13 +1706,13 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 // ------------------------------------------------------------------------
 // __global__ wrappers
 // ------------------------------------------------------------------------
-template <bool BF16, int H, bool PRE, int MT>
-__global__ __launch_bounds__(256, PRE ? 1 : (BF16 ? (MT > 1 ? 4 : 6) : 3)) void k_backward(const TrainerDesc *__restrict__ Dp,
+template <bool BF16, int H, bool PRE>
+__global__ __launch_bounds__(256, PRE ? 1 : (BF16 ? 6 : 3)) void k_backward(const TrainerDesc *__restrict__ Dp,
                                                                             const DevArgs *__restrict__ Ap,
                                                                             DevCtr *__restrict__ Cp, const int nslab,
                                                                             const int ntrain) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  backward_body<BF16, H, PRE, MT>(Dp + blockIdx.y, Cp + blockIdx.y, (int)blockIdx.x, smem, nslab, ntrain);
+  backward_body<BF16, H, PRE>(Dp + blockIdx.y, Cp + blockIdx.y, (int)blockIdx.x, smem, nslab, ntrain);
 }
 
 template <bool BF16, bool LAT>
@@ -1849,25 +1838,17 @@ hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD
 }
 hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
                            DevCtr *c, int n_seeds, hipStream_t st) {
-  static const int forced_pre = getenv("IQLHIP_BWD_PRE") ? atoi(getenv("IQLHIP_BWD_PRE")) : -1;  // A/B knobs
-  static const int forced_mt = getenv("IQLHIP_BWD_MT") ? atoi(getenv("IQLHIP_BWD_MT")) : 0;
-  // measured: no difference for one seed (63.2k either way), K = 8 170.2k against 165.1k
-  const bool group = (int64_t)D.B * n_seeds >= 1024;
-  const bool pre = forced_pre >= 0 ? forced_pre != 0 : !group;
-  // slabs per work-group: 2 in group launches (the one-seed variant keeps the early operands)
-  int mt = forced_mt ? forced_mt : (group ? 2 : 1);
-  if (pre || mt != 2 || (D.B / SLAB) % 2) mt = 1;
-  const int nsg = D.B / SLAB / mt;
-  const int grid = 8 * ((layer2_parts(D.H) * D.ntrain + 7) / 8) * nsg;
+  const int grid = 8 * ((layer2_parts(D.H) * D.ntrain + 7) / 8) * (D.B / SLAB);
   const size_t sm = bwd_smem_bytes(bf16, D.H);
-#define CALL(BF, HH)                                                                                                \
-  do {                                                                                                              \
-    if (pre)                                                                                                        \
-      hipLaunchKernelGGL((k_backward<BF, HH, true, 1>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsg, D.ntrain);  \
-    else if (mt == 2)                                                                                               \
-      hipLaunchKernelGGL((k_backward<BF, HH, false, 2>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsg, D.ntrain); \
-    else                                                                                                            \
-      hipLaunchKernelGGL((k_backward<BF, HH, false, 1>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, nsg, D.ntrain); \
+  static const int forced_pre = getenv("IQLHIP_BWD_PRE") ? atoi(getenv("IQLHIP_BWD_PRE")) : -1;  // A/B knob
+  // measured: no difference for one seed (63.2k either way), K = 8 170.2k against 165.1k
+  const bool pre = forced_pre >= 0 ? forced_pre != 0 : (int64_t)D.B * n_seeds < 1024;
+#define CALL(BF, HH)                                                                                                     \
+  do {                                                                                                                   \
+    if (pre)                                                                                                             \
+      hipLaunchKernelGGL((k_backward<BF, HH, true>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain);  \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((k_backward<BF, HH, false>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain); \
   } while (0)
   DISPATCH_H(bf16, D.H, CALL);
 #undef CALL
