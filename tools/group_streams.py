@@ -28,7 +28,12 @@ def masked_stream(g, G):
     mask = (C.c_uint32 * words)()
     for cu in range(n_cu):
         # "interleave": CU i belongs to stream i % G; "block": contiguous ranges
-        owner = cu % G if CU_MASK == "interleave" else cu * G // n_cu
+        if CU_MASK == "interleave":
+            owner = cu % G
+        elif CU_MASK.startswith("run"):  # runs of r consecutive CUs alternate between the streams
+            owner = (cu // int(CU_MASK[3:])) % G
+        else:
+            owner = cu * G // n_cu
         if owner == g:
             mask[cu // 32] |= 1 << (cu % 32)
     st = C.c_void_p()
