@@ -242,9 +242,11 @@ int iqlhip_group_train_steps(iqlhip_group *g, const iqlhip_replay_view *views, i
                              const int64_t *const *idx, const uint8_t *const *dropout_keep,
                              float *const *losses_out, int32_t graph_unroll, void *stream);
 
-/* A HIP stream confined to one slice of the compute units: CU i of the current device belongs
- * to slice i % n_slices (every slice spans all XCDs and memory channels).  Two seed groups
- * stepped on the two halves of the chip overlap one group's HBM-bound update with the other's
+/* A HIP stream confined to one slice of the compute units: bit i of the CU mask belongs to
+ * slice i % n_slices.  The mask enumerates the CUs round-robin over the 8 XCDs, so two slices
+ * are the even and the odd XCDs: each sub-group keeps four L2s to itself and all memory channels
+ * (slices that split every XCD in half instead measured 180k steps/s against 209k).  Two seed
+ * groups stepped on the two slices overlap one group's HBM-bound update with the other's
  * latency-bound forward / backward: 8 seeds as 2 x 4 measured 205k steps/s against 171k as one
  * group of 8 on the whole chip (tools/group_streams.py).  No counterpart in the reference (its
  * AGENTS_PER_GPU processes share the GPU unmanaged).  Destroy with iqlhip_stream_destroy.   */

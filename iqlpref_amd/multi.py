@@ -14,8 +14,9 @@ is bit-identical to running it alone.  Two execution modes:
     every trainer replays its own hipGraph on its own HIP stream; the launches interleave.
 ``mode="split"`` (``n_streams=G``, default 2)
     G sub-groups, each stepped by its own launch sequence on its own HIP stream, every stream
-    confined to its own slice of the compute units (CU i belongs to slice i % G,
-    ``iqlhip_stream_create_cu_slice``).  The sub-groups never share a CU, only the memory system:
+    confined to its own slice of the compute units (bit i of the CU mask belongs to slice i % G,
+    ``iqlhip_stream_create_cu_slice``; the mask runs round-robin over the 8 XCDs, so two slices
+    are the even and the odd XCDs).  The sub-groups share no CU and no L2, only the memory system:
     one's HBM-bound k_update runs beside the other's latency-bound k_forward / k_backward.
     Measured (bench.py agents leg): 8 seeds as 2 x 4 205k steps/s against 171k as one group of 8;
     4 seeds as 2 x 2 145k against 130k.  Two slices are the
