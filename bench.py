@@ -403,7 +403,7 @@ def agents_leg(ia, torch, tr, buf, device, seed, args, unroll, bytes_step):
     for k_ in sorted({2, 4, A_}):  # smaller groups first, for the scaling of the aggregate with K
         if k_ >= A_:
             break
-        g_ = ia.SeedGroup(trs[:k_])
+        g_ = ia.SeedGroup(trs[:k_], mode="group")
         scan[str(k_)] = rate(g_, k_, 5_000)
         g_.close()
         if k_ >= 4:
@@ -417,7 +417,7 @@ def agents_leg(ia, torch, tr, buf, device, seed, args, unroll, bytes_step):
         v_split = rate(gs, A_, n_multi)
         scan["%d (2 CU slices x %d)" % (A_, A_ // 2)] = v_split
         gs.close()
-    group = ia.SeedGroup(trs)
+    group = ia.SeedGroup(trs, mode="group")
     v_group = rate(group, A_, n_multi)
     scan[str(A_)] = v_group
     v = max(v_group, v_split or 0.0)

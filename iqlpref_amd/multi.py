@@ -6,13 +6,13 @@ the reference runs several W&B agents per GPU for the same reason
 The trainers share nothing (own arenas, own Philox stream) and the arithmetic of every seed
 is bit-identical to running it alone.  Two execution modes:
 
-``mode="group"`` (default when the trainers have one shape)
+``mode="group"`` (default for two or three trainers of one shape)
     ONE launch sequence steps all seeds: every kernel of the step runs with gridDim.y = K
     (``iqlhip_group_train_steps``).  K x the work-groups per launch, one third of the kernel
     boundaries per seed-step.
 ``mode="streams"``
     every trainer replays its own hipGraph on its own HIP stream; the launches interleave.
-``mode="split"`` (``n_streams=G``, default 2)
+``mode="split"`` (``n_streams=G``, default 2; the default mode from four trainers of one shape on)
     G sub-groups, each stepped by its own launch sequence on its own HIP stream, every stream
     confined to its own slice of the compute units (bit i of the CU mask belongs to slice i % G,
     ``iqlhip_stream_create_cu_slice``; the mask runs round-robin over the 8 XCDs, so two slices
@@ -67,8 +67,8 @@ class SeedGroup:
         if len({id(t) for t in trainers}) != len(trainers):
             raise ValueError("a trainer may appear only once in a SeedGroup")
         one_shape = len({_shape_key(t) for t in trainers}) == 1 and len(trainers) <= _lib.MAX_GROUP
-        if mode is None:
-            mode = "group" if one_shape else "streams"
+        if mode is None:  # the fastest arrangement measured for the shape at hand
+            mode = ("split" if len(trainers) >= 4 else "group") if one_shape else "streams"
         if mode not in ("group", "streams", "split"):
             raise ValueError("mode must be 'group', 'streams' or 'split'")
         if mode in ("group", "split") and not one_shape:

@@ -17,14 +17,14 @@ trs = [bench.build_trainer(ia, torch, dev, 10 + i, "bf16") for i in range(8)]
 if "--group-first" in sys.argv:  # bench.py's order: groups come and go before the first split group
     trs[0].train_steps(buf, 2000, bench.BATCH, return_losses=False, graph_unroll=50)
     for k in (2, 4):
-        g = ia.SeedGroup(trs[:k])
+        g = ia.SeedGroup(trs[:k], mode="group")
         print("group", k, rate(g, k, 5000), flush=True)
         g.close()
 g = ia.SeedGroup(trs, mode="split", n_streams=2)
 print("fresh split 2x4", rate(g, 8, 10000), flush=True)
 print("again", rate(g, 8, 10000), flush=True)
 g.close()
-g = ia.SeedGroup(trs)
+g = ia.SeedGroup(trs, mode="group")
 print("group 1x8", rate(g, 8, 10000), flush=True)
 g.close()
 g = ia.SeedGroup(trs, mode="split", n_streams=2)
