@@ -1,3 +1,7 @@
+"""Diagnostic: does SeedGroup(mode="split") keep its speed when it is created after other groups
+came and went?  (CU-slice streams created after a stream had been destroyed once shared a hardware
+queue: 91k instead of 190k steps/s; the library now keeps one capture stream per thread and the
+slice streams for the life of the process.)  Usage on the GPU box: python tools/split_dbg.py [--group-first]"""
 import os, sys, time, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
