@@ -6,20 +6,20 @@ the reference runs several W&B agents per GPU for the same reason
 The trainers share nothing (own arenas, own Philox stream) and the arithmetic of every seed
 is bit-identical to running it alone.  Two execution modes:
 
-``mode="group"`` (default for two or three trainers of one shape)
+``mode="group"``
     ONE launch sequence steps all seeds: every kernel of the step runs with gridDim.y = K
     (``iqlhip_group_train_steps``).  K x the work-groups per launch, one third of the kernel
     boundaries per seed-step.
 ``mode="streams"``
     every trainer replays its own hipGraph on its own HIP stream; the launches interleave.
-``mode="split"`` (``n_streams=G``, default 2; the default mode from four trainers of one shape on)
+``mode="split"`` (``n_streams=G``, default 2; the default mode for trainers of one shape)
     G sub-groups, each stepped by its own launch sequence on its own HIP stream, every stream
     confined to its own slice of the compute units (bit i of the CU mask belongs to slice i % G,
     ``iqlhip_stream_create_cu_slice``; the mask runs round-robin over the 8 XCDs, so two slices
     are the even and the odd XCDs).  The sub-groups share no CU and no L2, only the memory system:
     one's HBM-bound k_update runs beside the other's latency-bound k_forward / k_backward.
-    Measured (bench.py agents leg): 8 seeds as 2 x 4 205k steps/s against 171k as one group of 8;
-    4 seeds as 2 x 2 145k against 130k.  Two slices are the
+    Measured (tools/group_streams.py, tools/group_scan.py): 2 / 4 / 8 / 16 seeds as two sub-groups
+    107k / 160k / 202k / 250k steps/s against 93k / 130k / 171k / 204k as one group.  Two slices are the
     sweet spot (three do not divide the chip's 8 XCDs evenly, four leave each sub-group too few CUs).
 """
 import ctypes as C
@@ -68,7 +68,7 @@ class SeedGroup:
             raise ValueError("a trainer may appear only once in a SeedGroup")
         one_shape = len({_shape_key(t) for t in trainers}) == 1 and len(trainers) <= _lib.MAX_GROUP
         if mode is None:  # the fastest arrangement measured for the shape at hand
-            mode = ("split" if len(trainers) >= 4 else "group") if one_shape else "streams"
+            mode = ("split" if len(trainers) >= 2 else "group") if one_shape else "streams"
         if mode not in ("group", "streams", "split"):
             raise ValueError("mode must be 'group', 'streams' or 'split'")
         if mode in ("group", "split") and not one_shape:

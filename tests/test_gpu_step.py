@@ -456,7 +456,7 @@ def test_seed_group_injected_indices_and_own_buffers(gh):
                             graph_unroll=0).cpu().numpy()
     np.testing.assert_allclose(want, d["losses"], rtol=TOL["fp32"]["lg"])  # = the reference's trajectory
     bufs = [gh.make_buffer(hyper, data) for _ in range(3)]
-    group = ia.SeedGroup([gh.make_trainer(hyper, nets, "fp32") for _ in range(3)])
+    group = ia.SeedGroup([gh.make_trainer(hyper, nets, "fp32") for _ in range(3)], mode="group")
     assert group.mode == "group"
     # member 1 samples on the device (no injected inputs): it must differ, the others must not
     got = group.train_steps(bufs, K, B, indices=[idx, None, idx], dropout_keep=[keep, None, keep],
@@ -470,6 +470,7 @@ def test_seed_group_injected_indices_and_own_buffers(gh):
     with pytest.raises(ValueError):
         ia.SeedGroup([solo, other], mode="group")
     assert ia.SeedGroup([solo, other]).mode == "streams"
+    assert ia.SeedGroup([gh.make_trainer(hyper, nets, "fp32") for _ in range(2)]).mode == "split"  # the default
 
 
 def test_trainer_lifecycle_does_not_leak(gh):
@@ -531,8 +532,8 @@ def test_consecutive_calls_continue_each_other(gh):
     c.train_steps(buf, 15, B, return_losses=False, graph_unroll=0)
     assert not torch.equal(a._params, c._params)  # (the second buffer did change the run)
     # a group continues itself the same way
-    g1 = ia.SeedGroup([gh.make_trainer(hyper, nets, "bf16", seed=s) for s in (3, 4)])
-    g2 = ia.SeedGroup([gh.make_trainer(hyper, nets, "bf16", seed=s) for s in (3, 4)])
+    g1 = ia.SeedGroup([gh.make_trainer(hyper, nets, "bf16", seed=s) for s in (3, 4)], mode="group")
+    g2 = ia.SeedGroup([gh.make_trainer(hyper, nets, "bf16", seed=s) for s in (3, 4)], mode="group")
     g1.train_steps(buf, 12, B, graph_unroll=4)
     for n in (4, 4, 3, 1):
         g2.train_steps(buf, n, B, graph_unroll=4)
