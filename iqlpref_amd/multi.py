@@ -209,7 +209,12 @@ class SeedGroup:
     def _ensure_slice_streams(self):
         if self._streams:
             return
-        self._streams = _slice_streams(self._lib, self._dev, len(self._children))
+        try:
+            self._streams = _slice_streams(self._lib, self._dev, len(self._children))
+        except Exception as e:  # no CU-masked streams here: plain streams keep the results, not the speed
+            import warnings
+            warnings.warn(f"SeedGroup(mode='split'): CU-slice streams unavailable ({e}); using plain streams")
+            self._streams = [torch.cuda.Stream(device=self._dev) for _ in self._children]
 
     def _train_split(self, bufs, n_steps, batch_size, idx, keep, return_losses, graph_unroll):
         self._ensure_slice_streams()
