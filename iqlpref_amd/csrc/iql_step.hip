@@ -1383,11 +1383,10 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     // The operand fragments of this wave's first two in-feature tiles (16-row strips: all of
     // them) are requested up front, unconditionally (clamped indices): guards only around the MFMAs.
     constexpr int TB = NT < 2 ? NT : 2;
-    constexpr int SKC = LAT ? UKC : UKC / 2;  // k-steps per register chunk (see TKC below)
     auto chunk = [&](const int k0) {
-      uint4 zf[SKC], xf[TB][SKC];
+      uint4 zf[UKC], xf[TB][UKC];
 #pragma unroll
-      for (int ks = 0; ks < SKC; ++ks) {
+      for (int ks = 0; ks < UKC; ++ks) {
         const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
         zf[ks] = ldg16(Zsrc + frag_off<P>((o0 >> 4) + wo, kk, nk, lane));
       }
@@ -1395,14 +1394,14 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       for (int tb = 0; tb < TB; ++tb) {
         const int tt = th + UWPO * tb < nit ? th + UWPO * tb : nit - 1;
 #pragma unroll
-        for (int ks = 0; ks < SKC; ++ks) {
+        for (int ks = 0; ks < UKC; ++ks) {
           const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
           xf[tb][ks] = ldg16(Xsrc + frag_off<P>(tt, kk, nk, lane));
         }
       }
       if (th == 0) {
 #pragma unroll
-        for (int ks = 0; ks < SKC; ++ks) {
+        for (int ks = 0; ks < UKC; ++ks) {
           if (k0 + ks < nk) {  // bias gradient = row sums of dZ^T
             if constexpr (BF16) {
               const uint32_t w[4] = {zf[ks].x, zf[ks].y, zf[ks].z, zf[ks].w};
@@ -1420,7 +1419,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       for (int tb = 0; tb < TB; ++tb) {
         if (th + UWPO * tb < nit) {
 #pragma unroll
-          for (int ks = 0; ks < SKC; ++ks)
+          for (int ks = 0; ks < UKC; ++ks)
             if (k0 + ks < nk) P::mma(xf[tb][ks], zf[ks], acc[tb]);
         }
       }
@@ -1428,14 +1427,14 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 #pragma unroll
       for (int tb = TB; tb < NT; ++tb) {
         if (th + UWPO * tb < nit) {
-          uint4 xg[SKC];
+          uint4 xg[UKC];
 #pragma unroll
-          for (int ks = 0; ks < SKC; ++ks) {
+          for (int ks = 0; ks < UKC; ++ks) {
             const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
             xg[ks] = ldg16(Xsrc + frag_off<P>(th + UWPO * tb, kk, nk, lane));
           }
 #pragma unroll
-          for (int ks = 0; ks < SKC; ++ks)
+          for (int ks = 0; ks < UKC; ++ks)
             if (k0 + ks < nk) P::mma(xg[ks], zf[ks], acc[tb]);
         }
       }
@@ -1445,7 +1444,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     if (th < nit) {
       chunk(0);  // straight-line first chunk: no loop pre-header to drain the state loads in
 #pragma unroll 1
-      for (int k0 = SKC; k0 < nk; k0 += SKC) chunk(k0);
+      for (int k0 = UKC; k0 < nk; k0 += UKC) chunk(k0);
     }
     if constexpr (!LAT) load_state();
     // C/D layout: lane (r, q) of acc[tb] holds dW[o0 + 16 wo + r][16 (th + 2 tb) + 4 q + k]
@@ -1513,9 +1512,6 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   // ---- 2. dW^T tile on MFMA: A = layer input X^T, B = dZ^T (fragment-major) ----
   const T *Xsrc = reinterpret_cast<const T *>(it.Xsrc);
   const T *Zsrc = reinterpret_cast<const T *>(it.Zsrc);
-  // k-steps per register chunk: all of a bf16 batch-256 product at once for one seed; half of
-  // them in group launches (48 instead of 96 operand registers: more work-groups per CU)
-  constexpr int TKC = LAT ? UKC : UKC / 2;
   // wave (wo, wi) = (wave >> 1, wave & 1): in-feature tile wi x out-feature tiles UNB wo .. + UNB
   const int wo = wave >> 1, wi = wave & 1;
   const int ib = i0 + 16 * wi, ob = o0 + 16 * UNB * wo;
@@ -1537,18 +1533,18 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   // LDS hand-over to the row-ordered Adam pass) then start as soon as the fragments are in, while
   // the state is still streaming (+0.8 % measured).  First chunk straight-line: a loop
   // pre-header would drain every pending load.
-  auto load_frags = [&](const int k0, uint4(&xf)[TKC], uint4(&zf)[TKC][UNB]) {
+  auto load_frags = [&](const int k0, uint4(&xf)[UKC], uint4(&zf)[UKC][UNB]) {
 #pragma unroll
-    for (int ks = 0; ks < TKC; ++ks) {
+    for (int ks = 0; ks < UKC; ++ks) {
       const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
       xf[ks] = ldg16(Xsrc + frag_off<P>(ib >> 4, kk, nk, lane));
 #pragma unroll
       for (int b = 0; b < UNB; ++b) zf[ks][b] = ldg16(Zsrc + frag_off<P>(ot[b], kk, nk, lane));
     }
   };
-  auto mma_frags = [&](const int k0, const uint4(&xf)[TKC], const uint4(&zf)[TKC][UNB]) {
+  auto mma_frags = [&](const int k0, const uint4(&xf)[UKC], const uint4(&zf)[UKC][UNB]) {
 #pragma unroll
-    for (int ks = 0; ks < TKC; ++ks) {
+    for (int ks = 0; ks < UKC; ++ks) {
       if (k0 + ks < nk) {
 #pragma unroll
         for (int b = 0; b < UNB; ++b) {
@@ -1571,7 +1567,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   // (Tried: the operand panels of a tile through LDS-DMA -- 48 distinct fragments instead of the
   // 128 the eight waves load between them.  No gain: 3.24 vs 3.14 us per tile work-group, the
   // wait for ALL fragments plus a barrier costs what the L1 port saves.)
-  uint4 xf0[TKC], zf0[TKC][UNB];
+  uint4 xf0[UKC], zf0[UKC][UNB];
   load_frags(0, xf0, zf0);
   __builtin_amdgcn_sched_barrier(0);
 
@@ -1616,8 +1612,8 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   __builtin_amdgcn_sched_barrier(0);
   mma_frags(0, xf0, zf0);
 #pragma unroll 1
-  for (int k0 = TKC; k0 < nk; k0 += TKC) {
-    uint4 xf[TKC], zf[TKC][UNB];
+  for (int k0 = UKC; k0 < nk; k0 += UKC) {
+    uint4 xf[UKC], zf[UKC][UNB];
     load_frags(k0, xf, zf);
     mma_frags(k0, xf, zf);
   }
@@ -1720,7 +1716,7 @@ __global__ __launch_bounds__(256, PRE ? 1 : (BF16 ? 6 : 3)) void k_backward(cons
 }
 
 template <bool BF16, bool LAT>
-__global__ __launch_bounds__(LAT ? 512 : 256, LAT ? 2 : (BF16 ? 6 : 3)) void k_update(const TrainerDesc *__restrict__ Dp,
+__global__ __launch_bounds__(LAT ? 512 : 256, LAT ? 2 : (BF16 ? 4 : 3)) void k_update(const TrainerDesc *__restrict__ Dp,
                                                              const DevArgs *__restrict__ Ap,
                                                              DevCtr *__restrict__ Cp,
                                                              const UpdItem *__restrict__ items, int n_items) {
