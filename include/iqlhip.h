@@ -288,6 +288,14 @@ typedef struct {
   int32_t hidden_act; /* 0 relu, 1 tanh; 8 + i: entry i of reward_models/q_mlp.py:121-130
                          (cos, tanh, relu, softplus, sin, leaky_relu, swish, none)  */
   int32_t out_act;    /* 0 none, 1 tanh; 8 + i as above                          */
+  /* nn.Dropout(p) behind every hidden activation, as a module in train mode applies it
+   * (ref:436-437; GaussianPolicy.act in train mode, ref:476-482): dropout_p <= 0 disables.
+   * Masks: Philox4x32-10 keyed by dropout_seed, counter (row, dropout_call, unit / 4 | layer << 16,
+   * stream 3) -- oracle/philox.py:mlp_dropout_keep; a caller passes a fresh dropout_call per
+   * forward.  Kept values are multiplied by float(1 / (1 - p)) (ATen _dropout_impl).            */
+  float dropout_p;
+  uint32_t dropout_call;
+  uint64_t dropout_seed;
 } iqlhip_mlp_desc;
 
 /* out[n][out_stride] (first dims[n_layers] columns) = MLP(x[n][x_stride]).  */
@@ -342,7 +350,11 @@ typedef struct {
  * over a window (custom_offline:172-192) equals the last-token value of its prefix of length
  * i + 1: per-position values are windows of growing length.
  * obs [n_rows][S], act [n_rows][A], win_start int64 [n_win], win_len int32
- * [n_win] (1 <= len <= query_length), win_t0 int32 [n_win] or NULL, all device.  */
+ * [n_win] (1 <= len <= query_length), win_t0 int32 [n_win] or NULL, all device.
+ * Precondition (the window arrays live on the device, the entry point cannot read them):
+ * win_start[w] >= 0, win_start[w] + win_len[w] <= n_rows, win_t0[w] >= 0,
+ * win_t0[w] + win_len[w] <= n_temb.  The kernel clamps every window into these bounds, so a
+ * window that violates them yields a value for the clamped window, never an out-of-bounds read. */
 int iqlhip_pt_relabel(const iqlhip_pt_weights *w, const float *obs, const float *act, int64_t n_rows,
                       const int64_t *win_start, const int32_t *win_len, const int32_t *win_t0,
                       int64_t n_win, int32_t query_length, float *out, void *stream);

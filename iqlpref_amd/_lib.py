@@ -17,7 +17,7 @@ N_TENSORS = 6 * (MAX_CRITICS + 2) + 1
 MLP_MAX_LAYERS = 8
 MAX_GROUP = 16
 ACT_FLAX_BASE = 8  # iqlhip_mlp_desc activation code 8 + i = entry i of reward_models/q_mlp.py:121-130
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ERR_INVALID = -1
 ERR_HIP = -2
@@ -53,7 +53,8 @@ class MlpDesc(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("dims", C.c_int32 * (MLP_MAX_LAYERS + 1)),
                 ("weights", C.c_void_p * MLP_MAX_LAYERS),
                 ("biases", C.c_void_p * MLP_MAX_LAYERS),
-                ("w_in_out", C.c_int32), ("hidden_act", C.c_int32), ("out_act", C.c_int32)]
+                ("w_in_out", C.c_int32), ("hidden_act", C.c_int32), ("out_act", C.c_int32),
+                ("dropout_p", C.c_float), ("dropout_call", C.c_uint32), ("dropout_seed", C.c_uint64)]
 
 
 class PtWeights(C.Structure):

@@ -95,7 +95,7 @@ static hipError_t capture_stream(hipStream_t *out) {
   return hipSuccess;
 }
 
-extern "C" int iqlhip_abi_version(void) { return 4; }
+extern "C" int iqlhip_abi_version(void) { return 5; }
 // sha256 prefix of csrc/* + include/iqlhip.h, stamped by iqlpref_amd/build.py: the Python side
 // refuses a library whose tag does not match the sources it sits beside
 #ifndef IQLHIP_BUILD_TAG
@@ -194,6 +194,48 @@ extern "C" int iqlhip_replay_sample(const iqlhip_replay_view *view, int32_t batc
 // ----------------------------------------------------------------- trainer --
 static void group_invalidate(struct iqlhip_group *g);
 
+// Bound on the work one caller can leave queued on a stream.  A train_steps call of n steps is
+// 3n kernel dispatches (graph nodes or eager launches) and returns without a host wait; a caller
+// that loops over such calls (bench.py's long regions, a seed-group sweep) used to be able to
+// queue 60,000+ dispatches.  Every WINDOW dispatches the call records an event and, before it
+// queues more, waits for the event of TWO windows ago: at most ~3 windows are ever outstanding,
+// the device never runs dry (a window is >= 1.5 ms of work), and the host blocks only when it is
+// that far ahead.  IQLHIP_MAX_INFLIGHT (dispatches) overrides the window total; 0 disables.
+struct Throttle {
+  static constexpr int NEV = 2;
+  hipEvent_t ev[NEV] = {};
+  bool used[NEV] = {};
+  int head = 0;
+  int64_t since = 0;  // dispatches queued since the last recorded event
+  static int64_t window() {
+    static const int64_t w = [] {
+      const char *e = getenv("IQLHIP_MAX_INFLIGHT");
+      const int64_t total = e ? atoll(e) : 6144;
+      return total <= 0 ? (int64_t)0 : (total / 3 > 0 ? total / 3 : (int64_t)1);
+    }();
+    return w;
+  }
+  // call after `n` dispatches have been queued on `st`
+  hipError_t queued(int64_t n, hipStream_t st) {
+    const int64_t w = window();
+    if (w == 0) return hipSuccess;
+    since += n;
+    if (since < w) return hipSuccess;
+    since = 0;
+    hipError_t e;
+    if (!ev[head] && (e = hipEventCreateWithFlags(&ev[head], hipEventDisableTiming)) != hipSuccess) return e;
+    if (used[head] && (e = hipEventSynchronize(ev[head])) != hipSuccess) return e;  // two windows ago
+    if ((e = hipEventRecord(ev[head], st)) != hipSuccess) return e;
+    used[head] = true;
+    head = (head + 1) % NEV;
+    return hipSuccess;
+  }
+  void destroy() {
+    for (auto &e : ev)
+      if (e) (void)hipEventDestroy(e), e = nullptr;
+  }
+};
+
 struct iqlhip_trainer {
   iqlhip_trainer_config cfg;
   iqlhip_arenas arenas;
@@ -228,6 +270,7 @@ struct iqlhip_trainer {
 
   int64_t total_it = 0;
   double lr_q, lr_v, lr_a_base;
+  Throttle throttle;
   // hipGraph of `graph_unroll` steps
   hipGraphExec_t gexec = nullptr;
   int graph_unroll = 0;
@@ -596,6 +639,7 @@ extern "C" int iqlhip_trainer_destroy(iqlhip_trainer *t) {
 
   for (auto &e : t->ev)
     if (e) (void)hipEventDestroy(e);
+  t->throttle.destroy();
   if (t->ws) (void)hipFree(t->ws);
   delete t;
   return 0;
@@ -756,10 +800,15 @@ static int run_steps(iqlhip_trainer *t, const DevArgs &args_in, int64_t n_steps,
       (void)hipGraphDestroy(g);
       t->graph_unroll = graph_unroll;
     }
-    for (; done + graph_unroll <= n_steps; done += graph_unroll) HIP_TRY(hipGraphLaunch(t->gexec, st));
+    for (; done + graph_unroll <= n_steps; done += graph_unroll) {
+      HIP_TRY(hipGraphLaunch(t->gexec, st));
+      HIP_TRY(t->throttle.queued(3 * (int64_t)graph_unroll, st));
+    }
   }
-  for (; done < n_steps; ++done)
+  for (; done < n_steps; ++done) {
     if (int rc = enqueue_step(t, st)) return rc;
+    HIP_TRY(t->throttle.queued(3, st));
+  }
   return 0;
 }
 
@@ -831,6 +880,7 @@ struct iqlhip_group {
   hipGraphExec_t gexec = nullptr;
   int graph_unroll = 0;
   hipStream_t cap_stream = nullptr;
+  Throttle throttle;
   DevArgs dev_args[IQLHIP_MAX_GROUP];  // what the device copies hold (see `continues`)
   bool dev_args_valid = false;
   // per-kernel HIP-event timing (diagnostic mode, eager launches)
@@ -896,6 +946,9 @@ extern "C" int iqlhip_group_create(iqlhip_group **out, iqlhip_trainer *const *tr
     g->tr[k] = t;
     t->group = g;
     t->ddesc = g->gdesc + k, t->dargs = g->gargs + k, t->dctr = g->gctr + k, t->ditems = g->gitems + (size_t)k * ni;
+    // the member's DevArgs slot has moved: its next solo call must send its arguments and stage
+    // its first batch again (`continues` would otherwise trust what the OLD slot held)
+    t->dev_args_valid = false;
     if (t->gexec) {  // the member's own graph holds the old descriptor addresses
       (void)hipGraphExecDestroy(t->gexec);
       t->gexec = nullptr;
@@ -915,12 +968,16 @@ extern "C" int iqlhip_group_destroy(iqlhip_group *g) {
     (void)hipMemcpy(t->own_dctr, t->dctr, sizeof(DevCtr), hipMemcpyDeviceToDevice);
     t->ddesc = t->own_ddesc, t->dargs = t->own_dargs, t->dctr = t->own_dctr, t->ditems = t->own_ditems;
     t->group = nullptr;
+    // own_dargs holds whatever the member's last solo call OUTSIDE the group sent (all zero if
+    // there was none: rows = NULL): a solo call after the group must never continue from it
+    t->dev_args_valid = false;
     if (t->gexec) {
       (void)hipGraphExecDestroy(t->gexec);
       t->gexec = nullptr;
     }
   }
   if (g->gexec) (void)hipGraphExecDestroy(g->gexec);
+  g->throttle.destroy();
   for (auto &e : g->ev)
     if (e) (void)hipEventDestroy(e);
   for (int k = 0; k < iqlhip_group::ARG_RING; ++k) {
@@ -1042,10 +1099,15 @@ extern "C" int iqlhip_group_train_steps(iqlhip_group *g, const iqlhip_replay_vie
       (void)hipGraphDestroy(gr);
       g->graph_unroll = graph_unroll;
     }
-    for (; done + graph_unroll <= n_steps; done += graph_unroll) HIP_TRY(hipGraphLaunch(g->gexec, st));
+    for (; done + graph_unroll <= n_steps; done += graph_unroll) {
+      HIP_TRY(hipGraphLaunch(g->gexec, st));
+      HIP_TRY(g->throttle.queued(3 * (int64_t)graph_unroll, st));
+    }
   }
-  for (; done < n_steps; ++done)
+  for (; done < n_steps; ++done) {
     if (int rc = group_enqueue_step(g, st)) return rc;
+    HIP_TRY(g->throttle.queued(3, st));
+  }
   for (int k = 0; k < g->K; ++k) g->tr[k]->total_it += n_steps;
   return 0;
 }
@@ -1139,6 +1201,8 @@ extern "C" int iqlhip_mlp_forward(const iqlhip_mlp_desc *d, const float *x, int6
     if (a < 0 || (a > 1 && a < 8) || a > 15) return fail(IQLHIP_ERR_INVALID, "activation code %d", a);
   if (x_stride < d->dims[0] || out_stride < d->dims[d->n_layers])
     return fail(IQLHIP_ERR_INVALID, "stride smaller than the row width");
+  if (!(d->dropout_p < 1.0f)) return fail(IQLHIP_ERR_INVALID, "dropout_p must be < 1");
+  if (d->dropout_p > 0.f && n > 0xffffffffLL) return fail(IQLHIP_ERR_UNSUPPORTED, "dropout: n must fit 32 bits");
   HIP_TRY(launch_mlp_f32(*d, x, n, x_stride, out, out_stride, (hipStream_t)stream));
   return 0;
 }
@@ -1179,6 +1243,7 @@ extern "C" int iqlhip_pt_relabel(const iqlhip_pt_weights *w, const float *obs, c
     return fail(IQLHIP_ERR_UNSUPPORTED, "inter_dim %d: must be a multiple of 256 up to 1024", w->inter_dim);
   if (w->state_dim < 1 || w->action_dim < 1 || w->state_dim + w->action_dim > 192)
     return fail(IQLHIP_ERR_UNSUPPORTED, "state/action dims");
+  if (w->n_temb < 1) return fail(IQLHIP_ERR_INVALID, "empty timestep table");
   if (!win_t0 && query_length > w->n_temb)
     return fail(IQLHIP_ERR_INVALID, "query_length exceeds the timestep table");
   if (pt_smem_bytes(*w, query_length) > 160 * 1024)

@@ -180,7 +180,7 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
   }
   return Philox4{c0, c1, c2, c3};
 }
-constexpr uint32_t STREAM_INDEX = 0, STREAM_DROPOUT1 = 1, STREAM_DROPOUT2 = 2;
+constexpr uint32_t STREAM_INDEX = 0, STREAM_DROPOUT1 = 1, STREAM_DROPOUT2 = 2, STREAM_MLP_DROPOUT = 3;
 
 __device__ __forceinline__ int64_t philox_index(uint64_t seed, uint64_t step, uint32_t row,
                                                 uint64_t n_rows) {

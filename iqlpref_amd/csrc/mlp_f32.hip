@@ -30,6 +30,12 @@ struct MlpArgs {
   int32_t hidden_act;  // 0 relu, 1 tanh
   int32_t out_act;     // 0 none, 1 tanh
   int32_t lda;         // LDS row stride (floats)
+  // nn.Dropout(p) behind every hidden activation (ref:436-437) in train mode: keep iff the
+  // element's Philox word >= drop_thr, kept values times 1 / (1 - p); drop_thr = 0: no dropout
+  uint32_t drop_thr;
+  float drop_scale;
+  uint64_t drop_seed;
+  uint32_t drop_call;
 };
 
 struct RepackArgs {
@@ -258,6 +264,25 @@ __global__ __launch_bounds__(256, 2) void k_mlp_f32(const MlpArgs M, const float
       }
       __syncthreads();
     }
+    if (M.drop_thr && !last) {
+      // Dropout of this hidden layer (oracle/philox.py mlp_dropout_keep): one Philox4x32 block per
+      // (row, 4 consecutive units); a rolled pass over LDS, the 64-fold unrolled epilogues stay lean
+      const int Nq = 4 * ntile;
+#pragma unroll 1
+      for (int e = tid; e < MROWS * Nq; e += 256) {
+        const int rr = e / Nq, cq = e - rr * Nq;
+        const uint64_t R = (uint64_t)(row0 + rr);
+        const Philox4 ph = philox4x32_10((uint32_t)R, M.drop_call, (uint32_t)cq | ((uint32_t)l << 16),
+                                         STREAM_MLP_DROPOUT, (uint32_t)M.drop_seed, (uint32_t)(M.drop_seed >> 32));
+        float4 v = *reinterpret_cast<float4 *>(buf + rr * lda + 4 * cq);
+        v.x = ph.x >= M.drop_thr ? v.x * M.drop_scale : 0.f;
+        v.y = ph.y >= M.drop_thr ? v.y * M.drop_scale : 0.f;
+        v.z = ph.z >= M.drop_thr ? v.z * M.drop_scale : 0.f;
+        v.w = ph.w >= M.drop_thr ? v.w * M.drop_scale : 0.f;
+        *reinterpret_cast<float4 *>(buf + rr * lda + 4 * cq) = v;
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -286,6 +311,12 @@ hipError_t launch_mlp_f32(const iqlhip_mlp_desc &d, const float *x, int64_t n, i
   R.w_in_out = d.w_in_out;
   M.hidden_act = d.hidden_act, M.out_act = d.out_act;
   M.lda = round_up(maxd, 16) + 4;
+  M.drop_thr = 0, M.drop_scale = 1.f, M.drop_seed = d.dropout_seed, M.drop_call = d.dropout_call;
+  if (d.dropout_p > 0.f) {  // the trainer's fp32 convention (api.hip): thr = p 2^32, scale = 1 / (1 - p)
+    const double thr = (double)d.dropout_p * 4294967296.0;
+    M.drop_thr = thr >= 4294967295.0 ? 0xffffffffu : (thr < 1.0 ? 1u : (uint32_t)thr);
+    M.drop_scale = 1.0f / (float)(1.0 - (double)d.dropout_p);
+  }
   hipLaunchKernelGGL(k_mlp_repack, dim3(64, d.n_layers), dim3(256), 0, st, R);
   // the activations [64][lda], or the partial tiles of a k-split output layer (4 waves x <= 3 n-tiles)
   size_t sm = (size_t)MROWS * M.lda * sizeof(float);

@@ -190,11 +190,28 @@ __global__ __launch_bounds__(64 * PT_WAVES, 4) void k_pt_relabel(const iqlhip_pt
     layer_norm_t(h, fvec + 4 * E, fvec + 5 * E, q, eps);  // block pre-LN
   };
 
+  // A window (start, len, t0) as the kernel uses it: clamped so that no row of obs / act and no
+  // entry of the timestep table outside the arrays is ever addressed, whatever a caller hands in
+  // (valid windows -- 1 <= len <= ql, start + len <= n_rows, t0 + len <= n_temb, the precondition
+  // stated in iqlhip.h -- pass through unchanged; a few scalar instructions per window).
+  auto load_window = [&](int64_t win, int64_t &start, int &len, int &t0) {
+    int l = win_len[win];
+    const int64_t cap = n_rows < (int64_t)W.n_temb ? n_rows : (int64_t)W.n_temb;
+    l = l > ql ? ql : l;
+    l = (int64_t)l > cap ? (int)cap : l;
+    l = l < 1 ? 1 : l;
+    int64_t s0 = win_start[win];
+    s0 = s0 < 0 ? 0 : (s0 > n_rows - l ? n_rows - l : s0);
+    int t = win_t0 ? win_t0[win] : 0;
+    t = t < 0 ? 0 : (t > W.n_temb - l ? W.n_temb - l : t);
+    start = s0, len = l, t0 = t;
+  };
+
   // ---- the query and the residual stream of a window's last action token, into buffer `pb` ----
   auto prepare_query = [&](int64_t win, int pb) {
-    const int64_t start = win_start[win];
-    const int len = win_len[win];
-    const int t0 = win_t0 ? win_t0[win] : 0;
+    int64_t start;
+    int len, t0;
+    load_window(win, start, len, t0);
     const int mt_ = (len - 1) >> 4;
     f32x4 x[4], h[4];
     embed_ln(1, mt_, start, len, t0, x, h);
@@ -328,9 +345,9 @@ __global__ __launch_bounds__(64 * PT_WAVES, 4) void k_pt_relabel(const iqlhip_pt
   __syncthreads();
 
   for (int64_t win = blockIdx.x; win < n_win; win += gridDim.x, par ^= 1, qb = qb == 2 ? 0 : qb + 1) {
-    const int64_t start = win_start[win];
-    const int len = win_len[win];
-    const int t0 = win_t0 ? win_t0[win] : 0;  // timestep of the window's first transition
+    int64_t start;
+    int len, t0;  // t0: timestep of the window's first transition
+    load_window(win, start, len, t0);
     const int nmt = (len + 15) >> 4;           // 16-token tiles per kind
     // the query: per lane the components that meet its key features 16 mt + 4 q + i
     f32x4 qv[4];

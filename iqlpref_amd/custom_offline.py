@@ -196,6 +196,27 @@ def modify_reward(dataset: Dict[str, np.ndarray], env_name: str, max_episode_ste
         dataset["rewards"] -= 1.0
 
 
+def evaluate(env, actor: nn.Module, num_episodes: int, seed: int, device: str) -> np.ndarray:
+    """cref:559-579: ``num_episodes`` sequential episodes of a gymnasium-API environment
+    (``reset(seed=seed + i)``), greedy actions from ``actor.act`` (one exact-fp32 forward on the GPU
+    per step), undiscounted returns.  The actor is handed back in train mode (cref:578)."""
+    actor.eval()
+    episode_rewards = []
+    try:
+        for i in range(num_episodes):
+            done = False
+            state, _ = env.reset(seed=seed + i)
+            episode_reward = 0.0
+            while not done:
+                state, reward, terminated, truncated, _ = env.step(actor.act(np.asarray(state), device))
+                done = terminated or truncated
+                episode_reward += reward
+            episode_rewards.append(episode_reward)
+    finally:
+        actor.train()
+    return np.asarray(episode_rewards)
+
+
 # --------------------------------------------------------------------------- #
 # buffer and trainer
 # --------------------------------------------------------------------------- #

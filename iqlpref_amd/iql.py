@@ -235,6 +235,13 @@ class ReplayBuffer:
         self._generation = _buffer_generation[0]  # the contents changed: no prefetched batch survives
         print(f"Dataset size: {n}")
 
+    def touch(self):
+        """Call after editing the contents in place through ``_states`` ... ``_dones`` (they are
+        views of the packed rows): the library may hold a batch prefetched from the old contents,
+        and only a new generation number makes the next ``train_steps`` call stage afresh."""
+        _buffer_generation[0] += 1
+        self._generation = _buffer_generation[0]
+
     def view(self) -> _lib.ReplayView:
         return _lib.ReplayView(ptr(self._rows), min(self._size, self._pointer), self._stride,
                                self._state_dim, self._action_dim, self._generation)
@@ -308,18 +315,23 @@ class MLP(nn.Module):
         return [m for m in self.net if isinstance(m, nn.Linear)]
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if self._dropout is not None and self.training and self._dropout > 0:
-            raise NotImplementedError(
-                "stand-alone forward with active dropout: call .eval() first "
-                "(the training step applies dropout inside ImplicitQLearning.train)")
         lin = self.linears()
+        drop = None
+        if self._dropout is not None and self.training and self._dropout > 0:
+            # a module in train mode applies its Dropout layers (ref:436-437; GaussianPolicy.act in
+            # train mode samples through them, ref:476-482): masks from the library's Philox stream
+            # keyed by the torch seed, a fresh one per call
+            self._drop_calls = getattr(self, "_drop_calls", 0) + 1
+            drop = (float(self._dropout), torch.initial_seed() & 0xFFFFFFFFFFFFFFFF,
+                    (self._drop_calls - 1) & 0xFFFFFFFF)
         y = mlp_forward_f32([l.weight for l in lin], [l.bias for l in lin], x,
-                            w_in_out=False, hidden_act=self._hidden_act, out_act=self._out_act)
+                            w_in_out=False, hidden_act=self._hidden_act, out_act=self._out_act, dropout=drop)
         return y.squeeze(-1) if self._squeeze else y
 
 
-def mlp_forward_f32(weights, biases, x, *, w_in_out, hidden_act=0, out_act=0) -> torch.Tensor:
-    """Exact-fp32 MLP forward of ``x`` [n, in] on the GPU (iqlhip_mlp_forward)."""
+def mlp_forward_f32(weights, biases, x, *, w_in_out, hidden_act=0, out_act=0, dropout=None) -> torch.Tensor:
+    """Exact-fp32 MLP forward of ``x`` [n, in] on the GPU (iqlhip_mlp_forward).
+    ``dropout`` = (p, seed, call): nn.Dropout(p) behind every hidden activation (train mode)."""
     lib = _lib.load()
     dev = _lib.require_gpu(x.device)
     lead = x.shape[:-1]
@@ -336,6 +348,8 @@ def mlp_forward_f32(weights, biases, x, *, w_in_out, hidden_act=0, out_act=0) ->
         d.dims[i + 1] = w.shape[1] if w_in_out else w.shape[0]
         d.weights[i], d.biases[i] = w.data_ptr(), b.data_ptr()
     d.w_in_out, d.hidden_act, d.out_act = int(w_in_out), hidden_act, out_act
+    if dropout is not None:
+        d.dropout_p, d.dropout_seed, d.dropout_call = dropout
     if x2.shape[1] != d.dims[0]:
         raise RuntimeError(f"input width {x2.shape[1]} does not match the first layer ({d.dims[0]})")
     n_out = d.dims[len(weights)]

@@ -147,4 +147,6 @@ def prepare_replay(dataset: Dict[str, np.ndarray], replay_buffer, *, env_name: s
     replay_buffer.load_device_arrays(obs, act, rew, nxt, term.to(torch.float32), mean, std)
     if mean is None:
         return 0, 1
+    if stats == "host":
+        return m, s  # numpy's own arrays (dtype included), as ref:1438-1448 hands them to wrap_env
     return mean.cpu().numpy(), std.cpu().numpy()

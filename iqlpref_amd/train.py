@@ -161,9 +161,10 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
     """ref:1393-1570.  ``dataset``: an already-built qlearning dataset (skips d4rl);
     ``raw_dataset``: an env.get_dataset()-style dict handed to the relabel functions;
     ``evaluate(actor, step) -> (scores, steps_to_goal)`` replaces eval_actor when gym is
-    not installed (None: evaluation is skipped); ``host_prep``: run the dataset preparation of
-    ref:1435-1456 in numpy on the host (the reference's arithmetic to the last bit) instead of the
-    device kernels of iqlpref_amd.prep (state statistics agree to ~1e-6, everything else exactly)."""
+    not installed (None: evaluation is skipped); ``host_prep``: run the whole dataset preparation of
+    ref:1435-1456 in numpy on the host instead of the device kernels of iqlpref_amd.prep (both give
+    the reference's values to the last bit: the default path takes the state statistics from numpy
+    and does the reward normalisation, z-scoring and packing on the device)."""
     # one process per GPU: under torchrun this rank owns cuda:<LOCAL_RANK>, and everything
     # below (process group, buffer, trainer, metric all-gather) lives there
     bound = D.local_device()
@@ -190,10 +191,13 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
         dataset["observations"] = normalize_states(dataset["observations"], state_mean, state_std)
         dataset["next_observations"] = normalize_states(dataset["next_observations"], state_mean, state_std)
         replay_buffer.load_d4rl_dataset(dataset)
-    else:  # the same on the device: one upload, the z-scoring fused into the buffer load
+    else:  # the same on the device: one upload, the z-scoring fused into the buffer load.  The state
+        # statistics are numpy's (ref:132-135, float32 row sums): with them every normalised state --
+        # and with that the whole trajectory -- is the reference's to the last bit; stats="device"
+        # (double accumulation, ~1e-6 away) stays available through iqlpref_amd.prep
         state_mean, state_std = prep.prepare_replay(
             dataset, replay_buffer, env_name=config.env, normalize_reward=config.normalize_reward,
-            normalize=config.normalize, eps=1e-3)
+            normalize=config.normalize, eps=1e-3, stats="host")
     if max_action is None:
         max_action = float(env.action_space.high[0])
 

@@ -76,3 +76,21 @@ def dropout_keep(seed, step, layer, batch, hidden, p):
     words = np.stack(r, axis=0).reshape(4, batch // 4, hidden)  # [word][row//4][unit]
     words = words.transpose(1, 0, 2).reshape(batch, hidden)
     return words >= thr
+
+
+STREAM_MLP_DROPOUT = 3
+
+
+def mlp_dropout_keep(seed, call, layer, n_rows, width, p):
+    """Keep mask [n_rows, width] of the Dropout behind hidden layer ``layer`` (0-based) of a
+    stand-alone MLP forward in train mode (iqlhip_mlp_desc.dropout_*; k_mlp_f32): one Philox
+    block per (row, 4 consecutive units), counter = (row, call, unit // 4 | layer << 16, stream 3),
+    output word unit % 4; kept iff word >= max(1, floor(p * 2**32))."""
+    thr = np.uint32(max(1, min(int(p * 4294967296.0), 0xFFFFFFFF)))
+    nq = (width + 3) // 4
+    rows = np.repeat(np.arange(n_rows, dtype=np.uint32), nq)
+    cq = np.tile(np.arange(nq, dtype=np.uint32), n_rows) | np.uint32(layer << 16)
+    r = philox4x32_10(rows, np.uint32(call & 0xFFFFFFFF), cq, np.uint32(STREAM_MLP_DROPOUT),
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    words = np.stack(r, axis=1).reshape(n_rows, nq * 4)[:, :width]
+    return words >= thr

@@ -297,28 +297,33 @@ def qlearning_dataset_pt(dataset, p, max_episode_steps, query_length, num_heads=
     return relabel_dataset(dataset, r, keep)
 
 
-def custom_qlearning_dataset(episodes, p, query_length, num_heads=4, eps=1e-5):
+def custom_qlearning_dataset(episodes, p, query_length, num_heads=4, eps=1e-5, value_fn=None):
     """algorithms/custom_offline/iql.py:158-225 (query_length > 1) with the restated PT as r_model.
     ``episodes``: list of dicts with observations [L+1,S], actions [L,A], terminations [L].
     Episodes no longer than the query are labelled by ONE forward over the whole episode (values
     at every position); longer ones by that forward for the first query_length steps and then one
-    rolling window per step with the TRUE timesteps i+1-QL .. i (custom_offline:197-211)."""
+    rolling window per step with the TRUE timesteps i+1-QL .. i (custom_offline:197-211).
+    ``value_fn(states, actions, timesteps, mask) -> [1, L]`` per-position values replaces the
+    restated PT (tests: the stand-in model the reference's own loop was recorded with, which
+    pins this loop -- windows, timesteps, which positions are kept -- to the reference)."""
+    if value_fn is None:
+        def value_fn(sts, acts, ts, am):
+            return pt_value_last(p, sts, acts, ts, am, num_heads, eps, all_positions=True)
     obs, nxt, acts, rews, dones = [], [], [], [], []
     for ep in episodes:
         o, a = np.asarray(ep["observations"], F32), np.asarray(ep["actions"], F32)
         L = a.shape[0]
         if L <= query_length:
-            r = pt_value_last(p, o[:-1][None], a[None], np.arange(L)[None], np.ones((1, L), F32),
-                              num_heads, eps, all_positions=True).reshape(L)
+            r = np.asarray(value_fn(o[:-1][None], a[None], np.arange(L)[None], np.ones((1, L), F32))).reshape(L)
         else:
             r = np.zeros(L, F32)
             QL = query_length
-            r[:QL] = pt_value_last(p, o[:-1][:QL][None], a[:QL][None], np.arange(QL)[None],
-                                   np.ones((1, QL), F32), num_heads, eps, all_positions=True).reshape(QL)
+            r[:QL] = np.asarray(value_fn(o[:-1][:QL][None], a[:QL][None], np.arange(QL)[None],
+                                         np.ones((1, QL), F32))).reshape(QL)
             for i in range(QL, L):
                 sl = slice(i - QL + 1, i + 1)
-                r[i] = pt_value_last(p, o[:-1][sl][None], a[sl][None], np.arange(i + 1 - QL, i + 1)[None],
-                                     np.ones((1, QL), F32), num_heads, eps)[0]
+                r[i] = np.asarray(value_fn(o[:-1][sl][None], a[sl][None], np.arange(i + 1 - QL, i + 1)[None],
+                                           np.ones((1, QL), F32))).reshape(QL)[-1]
         obs.append(o[:-1]), nxt.append(o[1:]), acts.append(a), rews.append(r.astype(F32))
         dones.append(np.asarray(ep["terminations"]))
     return {"observations": np.concatenate(obs), "actions": np.concatenate(acts),

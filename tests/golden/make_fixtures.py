@@ -28,6 +28,11 @@ import torch
 import torch.nn as nn
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from tests import fake_envs  # noqa: E402  (our deterministic stand-in environments)
+from tests.helpers import regen_inputs, synth_dataset, tensor_checks  # noqa: E402
 
 
 # --------------------------------------------------------------------------- #
@@ -72,7 +77,12 @@ def import_reference(ref_root):
         return m
 
     stub("d4rl")
-    stub("gym", Env=object)
+    # gym: what eval_actor / _make_eval_env / wrap_env touch (ref:140-161, 253-262, 289-295), backed
+    # by our deterministic stand-in environments (tests/fake_envs.py)
+    stub("gym", Env=object, make=lambda name: fake_envs.FakeGymEnv(name),
+         wrappers=types.SimpleNamespace(TransformObservation=fake_envs.TransformObservation,
+                                        TransformReward=fake_envs.TransformReward),
+         vector=types.SimpleNamespace(AsyncVectorEnv=fake_envs.SyncVectorEnv))
     stub("wandb")
     stub("pyrallis", wrap=lambda *a, **k: (lambda f: f))
     stub("optbnn")
@@ -107,24 +117,6 @@ def adam_state(opt, module):
             out[f"{n}/exp_avg_sq"] = st["exp_avg_sq"].detach().numpy().copy()
             out[f"{n}/step"] = np.asarray(float(st["step"]))
     return out
-
-
-def synth_dataset(rng, n, s_dim, a_dim, reward="normal"):
-    obs = rng.standard_normal((n, s_dim)).astype(np.float32)
-    nxt = rng.standard_normal((n, s_dim)).astype(np.float32)
-    act = rng.uniform(-1, 1, (n, a_dim)).astype(np.float32)
-    if reward == "normal":
-        rew = rng.standard_normal(n).astype(np.float32)
-    else:  # antmaze-like sparse, then -1 (normalize_reward=1)
-        rew = (rng.uniform(size=n) < 0.05).astype(np.float32) - 1.0
-    term = (rng.uniform(size=n) < 0.02)
-    return {
-        "observations": obs,
-        "actions": act,
-        "rewards": rew,
-        "next_observations": nxt,
-        "terminals": term,
-    }
 
 
 def run_trajectory(ref, *, s_dim, a_dim, hidden, batch, n_rows, k_steps, seed,
@@ -242,6 +234,50 @@ def big_summary(ref, fp32):
         else:
             keep[k] = v
     return keep, common
+
+
+# BASELINE configs at their full widths (H = 256): the reference's trajectories as strided
+# summaries.  Initial parameters and data are NOT stored: they are functions of the seed
+# (torch.manual_seed + the module constructors, numpy default_rng) and tests/helpers.regen_inputs
+# rebuilds them with OUR constructors; the fixture keeps per-tensor checksums of what the
+# reference started from, and the tests refuse to run on anything else.
+BIG = {
+    # config 1: halfcheetah-medium-v2 (configs/offline/iql/halfcheetah/medium_v2.yaml: beta 3, iql_tau 0.7)
+    "traj_cheetah_h256": dict(s_dim=17, a_dim=6, hidden=256, batch=256, n_rows=1024, k_steps=10, seed=21,
+                              beta=3.0, iql_tau=0.7, discount=0.99, tau=0.005, deterministic=False,
+                              dropout=None, max_steps=1_000_000, reward_kind="normal"),
+    # config 3: pen-human-v1 (configs/offline/iql/pen/human_v1.yaml: actor_dropout 0.1, beta 3, iql_tau 0.8)
+    "traj_pen_h256": dict(s_dim=45, a_dim=24, hidden=256, batch=256, n_rows=1024, k_steps=10, seed=22,
+                          beta=3.0, iql_tau=0.8, discount=0.99, tau=0.005, deterministic=False,
+                          dropout=0.1, max_steps=1_000_000, reward_kind="normal"),
+    # config 5's batch with the reference's TwinQ (E = 2), antmaze hyper-parameters
+    "traj_antmaze_b1024": dict(s_dim=29, a_dim=8, hidden=256, batch=1024, n_rows=4096, k_steps=10, seed=23,
+                               beta=10.0, iql_tau=0.9, discount=0.99, tau=0.005, deterministic=False,
+                               dropout=None, max_steps=1_000_000, reward_kind="sparse"),
+}
+
+
+def big_regen(ref, name, fp32):
+    cfg = BIG[name]
+    full = run_trajectory(ref, fp32=fp32, **cfg)
+    keep = {"regen_seed": np.asarray(cfg["seed"]), "reward_kind": np.asarray(cfg["reward_kind"])}
+    for k, v in full.items():
+        if k.startswith(("init/", "data/")):
+            keep["check/" + k] = tensor_checks(v)
+        elif k.startswith(("step1/", "final/")) and v.size > 2048:
+            keep[k + "#stride37"] = v.reshape(-1)[::37].copy()
+            keep[k + "#sum"] = np.asarray(v.astype(np.float64).sum())
+            keep[k + "#abssum"] = np.asarray(np.abs(v.astype(np.float64)).sum())
+        else:
+            keep[k] = v
+    # what the tests will rebuild must be what the reference started from, bit for bit
+    data, nets = regen_inputs(keep)
+    for k, v in data.items():
+        assert np.array_equal(v, full["data/" + k]), k
+    for pre, net in zip(("qf", "vf", "actor"), nets):
+        for k, v in net.items():
+            assert np.array_equal(v, full[f"init/{pre}/{k}"]), (pre, k)
+    return keep
 
 
 def per_op(ref):
@@ -496,6 +532,203 @@ def checkpoint_compat(ref, ckpt_path):
             "keys": np.asarray(sorted(ck.keys()), dtype="U")}
 
 
+def import_custom_reference(ref_root):
+    """algorithms/custom_offline/iql.py ("cref") with inert stubs for what is absent here
+    (gymnasium, minari, orbax, flax, jax, pyrallis, wandb, the iqlpref.reward_models loaders): its
+    torch / numpy parts -- ReplayBuffer, networks, ImplicitQLearning, soft_update, modify_reward,
+    qlearning_dataset, evaluate -- run as written."""
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    stub("gymnasium", Env=object,
+         wrappers=types.SimpleNamespace(TransformObservation=fake_envs.TransformObservation,
+                                        TransformReward=fake_envs.TransformReward))
+    stub("minari", MinariDataset=object)
+    stub("orbax")
+    stub("orbax.checkpoint")
+    sys.modules["orbax"].checkpoint = sys.modules["orbax.checkpoint"]
+    stub("pyrallis", wrap=lambda *a, **k: (lambda f: f))
+    stub("wandb")
+    stub("flax", nnx=types.SimpleNamespace())
+    stub("jax")
+    stub("iqlpref")
+    stub("iqlpref.reward_models")
+    stub("iqlpref.reward_models.pref_transformer", load_PT=None)
+    stub("iqlpref.reward_models.q_mlp", load_QMLP=None)
+    path = os.path.join(ref_root, "algorithms", "custom_offline", "iql.py")
+    spec = importlib.util.spec_from_file_location("ref_custom_iql", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.dont_write_bytecode = True
+    keep_path = list(sys.path)
+    spec.loader.exec_module(mod)
+    sys.path[:] = keep_path  # (the file prepends "../" to sys.path on import)
+    return mod
+
+
+def custom_offline_fixtures(cref):
+    """f4: the torch / numpy half of the custom_offline flavour, run by the reference itself."""
+    out = {}
+    # ---- K-step trajectory: fp32 (no autocast), convex Polyak, numpy-global-RNG sampler ----
+    S, A, H, B, N, K, seed = 29, 8, 64, 64, 1000, 10, 5
+    data = synth_dataset(np.random.default_rng(seed), N, S, A, "sparse")
+    buf = cref.ReplayBuffer(S, A, N + 7, "cpu")
+    buf.load_dataset(data)
+    torch.manual_seed(seed)
+    q, v = cref.TwinQ(S, A, hidden_dim=H), cref.ValueFunction(S, hidden_dim=H)
+    actor = cref.GaussianPolicy(S, A, 1.0, hidden_dim=H)
+    with torch.no_grad():
+        actor.log_std.copy_(torch.linspace(-0.5, 0.3, A))
+    vo = torch.optim.Adam(v.parameters(), lr=3e-4)
+    qo = torch.optim.Adam(q.parameters(), lr=3e-4)
+    ao = torch.optim.Adam(actor.parameters(), lr=3e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(ao, 1000)
+    trainer = cref.ImplicitQLearning(max_action=1.0, actor=actor, actor_optimizer=ao, actor_lr_scheduler=sched,
+                                     q_network=q, q_optimizer=qo, v_network=v, v_optimizer=vo, iql_tau=0.9,
+                                     beta=10.0, gamma=0.99, tau=0.005, device="cpu")
+    out.update(flat("traj/init/qf", params_of(q)))
+    out.update(flat("traj/init/vf", params_of(v)))
+    out.update(flat("traj/init/actor", params_of(actor)))
+    for k in ("observations", "actions", "rewards", "next_observations"):
+        out[f"traj/data/{k}"] = data[k]
+    out["traj/data/terminals"] = data["terminals"].astype(np.float32)
+    idx_all, losses, lrs = np.zeros((K, B), np.int64), np.zeros((K, 3)), np.zeros(K)
+    np.random.seed(seed)
+    for t in range(K):
+        st = np.random.get_state()
+        batch = buf.sample(B)                       # the reference's own sampler (cref:277-284)
+        after = np.random.get_state()
+        np.random.set_state(st)
+        idx = np.random.randint(0, N, size=B)       # ... replayed to learn which rows it drew
+        assert all(np.array_equal(x, y) for x, y in zip(np.random.get_state()[1:3], after[1:3]))
+        assert np.array_equal(batch[0].numpy(), data["observations"][idx])
+        idx_all[t] = idx
+        lrs[t] = ao.param_groups[0]["lr"]
+        log = trainer.train(batch)
+        losses[t] = [log["value_loss"], log["q_loss"], log["actor_loss"]]
+    out["traj/hyper"] = np.asarray([S, A, H, B, N, K, 10.0, 0.9, 0.99, 0.005, 0.0, -1.0, 1000], dtype=np.float64)
+    out["traj/np_seed"] = np.asarray(seed)
+    out["traj/indices"], out["traj/losses"], out["traj/actor_lr"] = idx_all, losses, lrs
+    out["traj/final_actor_lr"] = np.asarray(ao.param_groups[0]["lr"])
+    out.update(flat("traj/final/qf", params_of(q)))
+    out.update(flat("traj/final/vf", params_of(v)))
+    out.update(flat("traj/final/actor", params_of(actor)))
+    out.update(flat("traj/final/q_target", params_of(trainer.q_target)))
+    out.update(flat("traj/final/q_adam", adam_state(qo, q)))
+    sd = trainer.state_dict()
+    out["traj/state_dict_keys"] = np.asarray(sorted(sd.keys()))
+    out["traj/scheduler_last_epoch"] = np.asarray(sd["actor_lr_scheduler"]["last_epoch"])
+
+    # ---- soft_update (cref:85-87): (1 - tau) t + tau s ----
+    src, tgt = nn.Linear(5, 3), nn.Linear(5, 3)
+    out["soft/src_w"], out["soft/tgt_w"] = src.weight.detach().numpy().copy(), tgt.weight.detach().numpy().copy()
+    cref.soft_update(tgt, src, 0.005)
+    out["soft/out_w"] = tgt.weight.detach().numpy().copy()
+
+    # ---- modify_reward / return_reward_range (cref:127-155) ----
+    rng = np.random.default_rng(12)
+    rew = rng.standard_normal(64).astype(np.float32)
+    term = np.zeros(64, dtype=bool)
+    term[[9, 30, 31, 50]] = True
+    out["mr/rewards"], out["mr/terminals"] = rew, term
+    out["mr/range"] = np.asarray(cref.return_reward_range({"rewards": rew.copy(), "terminals": term}, 12))
+    for name in ("halfcheetah-medium-v2", "hopper-medium-v2", "antmaze-medium-diverse-v2", "D4RL/pen/human-v2"):
+        ds = {"rewards": rew.copy(), "terminals": term}
+        cref.modify_reward(ds, name, max_episode_steps=12)
+        out[f"mr/{name.replace('/', '_')}"] = ds["rewards"]
+
+    # ---- qlearning_dataset (cref:158-225) with stand-in reward models: what the loop hands the
+    # model call by call, and the dataset it builds from the answers ----
+    lengths = (3, 8, 9, 25, 1)
+    out["qd/lengths"] = np.asarray(lengths)
+    for ql in (8, 1):
+        eps = fake_envs.make_episodes(31, 6, 2, lengths)
+        calls = []
+        if ql > 1:
+            def r_model(sts, acts, ts, am, training=False):
+                calls.append((np.asarray(sts).copy(), np.asarray(acts).copy(), np.asarray(ts).copy(),
+                              np.asarray(am).copy()))
+                return {"value": fake_envs.fake_pt_values(sts, acts, ts, am)[..., None]}, None
+        else:
+            r_model = fake_envs.fake_markov_reward
+        ds = cref.qlearning_dataset(eps, r_model, ql)
+        for k, val in ds.items():
+            out[f"qd/ql{ql}/{k}"] = np.asarray(val)
+        if ql > 1:
+            out[f"qd/ql{ql}/call_len"] = np.asarray([c[0].shape[1] for c in calls])
+            out[f"qd/ql{ql}/call_t0"] = np.asarray([int(c[2][0, 0]) for c in calls])
+            out[f"qd/ql{ql}/call_ts_last"] = np.asarray([int(c[2][0, -1]) for c in calls])
+            out[f"qd/ql{ql}/call_first_state"] = np.stack([c[0][0, 0] for c in calls])
+            out[f"qd/ql{ql}/call_last_action"] = np.stack([c[1][0, -1] for c in calls])
+            out[f"qd/ql{ql}/call_mask_sum"] = np.asarray([float(c[3].sum()) for c in calls])
+
+    # ---- evaluate (cref:559-579): sequential episodes, gymnasium API ----
+    S, A = fake_envs.DIMS["pen-human-v1"]
+    torch.manual_seed(9)
+    pol = cref.GaussianPolicy(S, A, 0.8, hidden_dim=64, dropout=0.1)
+    with torch.no_grad():
+        pol.log_std.copy_(torch.linspace(-0.4, 0.2, A))
+    mean, std = np.linspace(-0.2, 0.2, S), np.linspace(0.8, 1.3, S)
+    env = cref.wrap_env(_SpacedEnv(fake_envs.FakeGymnasiumEnv("pen-human-v1")), state_mean=mean, state_std=std)
+    seen = []
+    real_step = env.step
+
+    def step(a):
+        seen.append(np.asarray(a).copy())
+        return real_step(a)
+    env.step = step
+    scores = cref.evaluate(env, pol, num_episodes=6, seed=40, device="cpu")
+    assert pol.training  # cref:578
+    out.update(flat("ev/actor", params_of(pol)))
+    out["ev/mean"], out["ev/std"] = mean, std
+    out["ev/scores"], out["ev/actions"] = scores, np.stack(seen)
+    return out
+
+
+class _SpacedEnv:
+    """cref:118 passes env.observation_space to TransformObservation: give the stand-in one."""
+
+    def __init__(self, env):
+        self.env, self.observation_space = env, None
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+
+def eval_fixtures(ref):
+    """f1: the reference's eval_actor (ref:265-341) driving the deterministic stand-in vector
+    environment (its gym.make / wrap_env / AsyncVectorEnv calls land in tests/fake_envs.py)."""
+    out = {}
+    for tag, name, det in (("antmaze", "antmaze-medium-diverse-v2", False),
+                           ("cheetah", "halfcheetah-medium-v2", True)):
+        S, A = fake_envs.DIMS[name]
+        torch.manual_seed(4)
+        cls = ref.DeterministicPolicy if det else ref.GaussianPolicy
+        actor = cls(S, A, 0.7, hidden_dim=64, dropout=0.1)
+        mean, std = np.linspace(-0.2, 0.2, S), np.linspace(0.8, 1.3, S)
+        made = []
+        real = sys.modules["gym"].vector.AsyncVectorEnv
+
+        def spy(fns):
+            made.append(real(fns))
+            return made[-1]
+        sys.modules["gym"].vector.AsyncVectorEnv = spy
+        try:
+            scores, steps = ref.eval_actor(name, actor, 0.7, mean, std, "cpu", n_episodes=17, seed=100, n_envs=5)
+        finally:
+            sys.modules["gym"].vector.AsyncVectorEnv = real
+        assert actor.training and made[0].closed
+        out.update(flat(f"{tag}/actor", params_of(actor)))
+        out[f"{tag}/mean"], out[f"{tag}/std"] = mean, std
+        out[f"{tag}/scores"], out[f"{tag}/steps_to_goal"] = scores, np.asarray(steps, dtype=np.int64)
+        out[f"{tag}/actions"] = np.stack(made[0].actions_seen)
+        out[f"{tag}/args"] = np.asarray([0.7, 17, 100, 5, float(det)])
+    return out
+
+
 def save(name, d):
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **d)
@@ -507,11 +740,25 @@ def main():
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--checkpoint-compat", default=None,
                     help="only write checkpoint_compat.npz from this checkpoint of our trainer")
+    ap.add_argument("--only", default=None,
+                    help="comma-separated subset: small, h256, big, per_op, dataset_ops, eval, custom")
     args = ap.parse_args()
     torch.set_num_threads(1)  # fixed summation order for the captured vectors
     ref = import_reference(args.ref)
     if args.checkpoint_compat:
         save("checkpoint_compat.npz", checkpoint_compat(ref, args.checkpoint_compat))
+        return
+    only = set(args.only.split(",")) if args.only else None
+    want = lambda what: only is None or what in only
+    if want("eval"):
+        save("eval_actor.npz", eval_fixtures(ref))
+    if want("custom"):
+        save("custom_offline.npz", custom_offline_fixtures(import_custom_reference(args.ref)))
+    if want("big"):
+        for name in BIG:
+            for fp32 in (True, False):
+                save(f"{name}_{'fp32' if fp32 else 'bf16'}.npz", big_regen(ref, name, fp32))
+    if only is not None and not (only & {"small", "h256", "per_op", "dataset_ops"}):
         return
 
     cfgs = {

@@ -44,7 +44,7 @@ def test_bf16_rounding_matches_torch():
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
-@pytest.mark.parametrize("name", helpers.TRAJ)
+@pytest.mark.parametrize("name", helpers.TRAJ + helpers.TRAJ_BIG)
 def test_trajectory_matches_reference(name, mode):
     d, hyper, data, nets = helpers.load_traj(name, mode)
     o = helpers.make_oracle(hyper, nets, mode)
@@ -62,7 +62,14 @@ def test_trajectory_matches_reference(name, mode):
         for k, v in pd.items():
             want, got = helpers.golden_param(d, f"final/{net}/{k}", v)
             assert want is not None
-            np.testing.assert_allclose(got, want.reshape(got.shape), atol=ptol, rtol=0)
+            if mode == "bf16" and hyper["hidden"] >= 256:
+                # a bf16 rounding tie that falls the other way under another summation order moves
+                # ONE gradient entry; Adam's early steps are sign-like, so that entry's parameter ends
+                # up to 2 lr per affected step away: a vanishing fraction may, none further than K lr
+                diff = np.abs(got - want.reshape(got.shape))
+                assert (diff > ptol).mean() < 2e-3 and diff.max() < hyper["k_steps"] * 3e-4 * 1.01, (net, k)
+            else:
+                np.testing.assert_allclose(got, want.reshape(got.shape), atol=ptol, rtol=0)
     for which, net in (("q", "q_adam"), ("v", "v_adam"), ("actor", "actor_adam")):
         for k, m in o.m[which].items():
             want, got = helpers.golden_param(d, f"final/{net}/{k}/exp_avg", m)
@@ -70,11 +77,18 @@ def test_trajectory_matches_reference(name, mode):
                 continue
             scale = np.abs(want).max() + 1e-30
             tol = 2e-5 if mode == "fp32" else 3e-2
-            assert np.abs(got - want.reshape(got.shape)).max() / scale < tol
             want2, got2 = helpers.golden_param(d, f"final/{net}/{k}/exp_avg_sq",
                                                o.v2[which][k])
             scale2 = np.abs(want2).max() + 1e-30
-            assert np.abs(got2 - want2.reshape(got2.shape)).max() / scale2 < tol
+            err = np.abs(got - want.reshape(got.shape)) / scale
+            err2 = np.abs(got2 - want2.reshape(got2.shape)) / scale2
+            if mode == "bf16" and hyper["hidden"] >= 256:
+                # (one relu'(z) that flips under another summation order moves one sample's share of
+                # a gradient entry: isolated entries may be off by more, see the parameters above)
+                assert (err > tol).mean() < 5e-3 and err.max() < 0.25, (which, k, err.max())
+                assert (err2 > tol).mean() < 5e-3 and err2.max() < 0.25, (which, k, err2.max())
+            else:
+                assert err.max() < tol and err2.max() < tol
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
