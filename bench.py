@@ -100,8 +100,10 @@ def cpu_baseline(data, seconds=12.0):
     except Exception:
         cores = os.cpu_count() or 1
     return {"value": steps / dt, "unit": "steps/s", "cores": int(cores), "kind": "port",
-            "sample": f"{steps} steps in {dt:.1f} s of oracle/iql_oracle.py (numpy fp32 BLAS), "
-                      f"same shapes (S=29 A=8 H=256 B=256, N=1M)",
+            "sample": f"{steps} steps in {dt:.1f} s of oracle/iql_oracle.py in mode=\"fp32\" (numpy fp32 BLAS: "
+                      f"the faster of its two modes; the GPU leg and the reference's CPU path run bf16 "
+                      f"autocast), same shapes (S=29 A=8 H=256 B=256, N=1M)",
+            "arithmetic": "fp32",
             "reference_in_container": REFERENCE_CPU}
 
 
@@ -359,6 +361,13 @@ def main():
                 out["agents_per_gpu"] = agents_leg(ia, torch, tr, buf, device, seed, args, unroll, bytes_step.value)
             except Exception as e:
                 out["agents_per_gpu"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and args.agents_per_gpu > 1:
+            # the same aggregate through the PRODUCT entry point: train(config, seeds_per_gpu=K)
+            # (iqlpref_amd/train.py; ensemble_sweeps/launch.sh:12 AGENTS_PER_GPU), log windows of 2500 steps
+            try:
+                out["train_seeds_per_gpu"] = train_leg(ia, data, device, args)
+            except Exception as e:
+                out["train_seeds_per_gpu"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.ensemble_q >= 2:
             try:
                 E_ = args.ensemble_q
@@ -388,6 +397,28 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def train_leg(ia, data, device, args):
+    """K seeds through train(config, seeds_per_gpu=K): steps/s between the first and the last log
+    window (setup -- upload, dataset preparation, trainer construction -- is outside the figure)."""
+    K_ = args.agents_per_gpu
+    log_freq, windows = 2_500, 9
+    cfg = ia.TrainConfig(env="antmaze-medium-diverse-v2", max_timesteps=log_freq * windows, log_freq=log_freq,
+                         eval_freq=10 ** 9, batch_size=BATCH, normalize_reward=0, normalize=True, seed=500,
+                         device=device, buffer_size=N_ROWS, **{k: HYPER[k] for k in ("beta", "iql_tau", "discount", "tau")})
+    stamps = []
+    t0 = time.perf_counter()
+    ia.train(cfg, dataset=data, state_dim=S_DIM, action_dim=A_DIM, max_action=1.0, precision=args.precision,
+             logger=lambda d, step: stamps.append((time.perf_counter(), step)) if d.get("seed") == 500 else None,
+             evaluate=None, seeds_per_gpu=K_)
+    total_s = time.perf_counter() - t0
+    dt = stamps[-1][0] - stamps[0][0]
+    steps = stamps[-1][1] - stamps[0][1]
+    return {"seeds_per_gpu": K_, "value": K_ * steps / dt, "unit": "steps/s", "steps_per_seed_timed": steps,
+            "log_freq": log_freq, "wall_s_with_setup": total_s,
+            "note": "aggregate steps/s of train(config, seeds_per_gpu=K) between its first and last log window "
+                    "(per-seed loss windows read back every log_freq steps); not `value` of the record"}
 
 
 def agents_leg(ia, torch, tr, buf, device, seed, args, unroll, bytes_step):

@@ -50,13 +50,18 @@ def needs_build():
     return built_tag() != source_tag()
 
 
-def build(force=False, verbose=True, stamps=False):
-    """stamps=True builds the diagnostic libiqlhip_stamps.so (tools/stamps.py), never the product."""
-    if not stamps and not force and not needs_build():
+def build(force=False, verbose=True, stamps=False, variant=None, defines=()):
+    """stamps=True builds the diagnostic libiqlhip_stamps.so (tools/stamps.py), never the product.
+    variant="x" + defines=["IQL_FOO=1"]: an experimental build libiqlhip_x.so for A/B runs
+    (tools/ab.sh, loaded through IQLHIP_LIB), never the product either."""
+    if not stamps and not variant and not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out = LIB.replace(".so", "_stamps.so") if stamps else LIB
     extra = ["-DIQL_STAMPS"] if stamps else []
+    if variant:
+        out = LIB.replace(".so", f"_{variant}{'_stamps' if stamps else ''}.so")
+        extra += [f"-D{d}" for d in defines]
     tag = source_tag(extra)
     cmd = [hipcc] + FLAGS + extra + [f'-DIQLHIP_BUILD_TAG="{tag}"', "-o", out] + \
           [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
@@ -67,4 +72,7 @@ def build(force=False, verbose=True, stamps=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, stamps="--stamps" in sys.argv)
+    # python -m iqlpref_amd.build [--force] [--stamps] [--variant NAME -DX=1 ...]
+    _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    build(force="--force" in sys.argv, stamps="--stamps" in sys.argv, variant=_variant,
+          defines=[a[2:] for a in sys.argv if a.startswith("-D")])

@@ -51,6 +51,15 @@ __device__ __forceinline__ uint2 ldg8(const void *p) {
 __device__ __forceinline__ void stg16(void *p, float4 v) {
   *(u32x4_t IQL_AS1 *)p = __builtin_bit_cast(u32x4_t, v);
 }
+// Write-through store (sc0 sc1): the bytes leave for memory as the store executes and the line is
+// NOT kept in this XCD's L2 -- for data whose next reader is another kernel on another XCD (or the
+// same kernel one step later), so that nothing of it is dirty when the kernel ends
+// (MI355X_MICROARCH.md: "stores of each flavour"; nt is not write-through).
+__device__ __forceinline__ void stg16_wt(void *p, float4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"((u32x4_t IQL_AS1 *)p),
+               "v"(__builtin_bit_cast(u32x4_t, v))
+               : "memory");
+}
 __device__ __forceinline__ void stg8(void *p, uint2 v) {
   *(u32x2_t IQL_AS1 *)p = __builtin_bit_cast(u32x2_t, v);
 }

@@ -1198,6 +1198,20 @@ __device__ __forceinline__ void write_adam_coef(const TrainerDesc &D, const DevA
   *out = c;
 }
 
+// The fp32 optimiser state (masters, moments, target) a tile writes is next read one step later by
+// the same tile's successor: IQL_WT_STATE (A/B build) stores it write-through so that the kernel
+// leaves nothing of it dirty for the release at the kernel boundary.
+#ifndef IQL_WT_STATE
+#define IQL_WT_STATE 0
+#endif
+__device__ __forceinline__ void state_store(float *p, float4 v) {
+#if IQL_WT_STATE
+  stg16_wt(p, v);
+#else
+  stg16(p, v);
+#endif
+}
+
 constexpr int UKC = 8;  // batch k-steps per register chunk in the weight-gradient GEMM
 
 // One work-group owns the gradient tile dW[o0..o0+64)[i0..i0+32) (192 work-groups
@@ -1660,11 +1674,11 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     if (o < Odim && i < Idim) {
       const int64_t e = it.off_w + (int64_t)o * Idim + i;
       const int64_t te = it.toff_w + (int64_t)o * Idim + i;
-      stg16(g_params + e, make_float4(p[0], p[1], p[2], p[3]));
-      stg16(g_m + e, make_float4(m[0], m[1], m[2], m[3]));
-      stg16(g_v + e, make_float4(v[0], v[1], v[2], v[3]));
+      state_store(g_params + e, make_float4(p[0], p[1], p[2], p[3]));
+      state_store(g_m + e, make_float4(m[0], m[1], m[2], m[3]));
+      state_store(g_v + e, make_float4(v[0], v[1], v[2], v[3]));
       if (g_grads) stg16(g_grads + e, make_float4(g[0], g[1], g[2], g[3]));
-      if (has_target) stg16(g_target + te, make_float4(tv[0], tv[1], tv[2], tv[3]));
+      if (has_target) state_store(g_target + te, make_float4(tv[0], tv[1], tv[2], tv[3]));
       // 4 consecutive k of one row are contiguous in the fragment-major copies
       store4T<BF16>(wc + fidx<P>(o, i, nkw), p);
       if (has_target) store4T<BF16>(tc + fidx<P>(o, i, nkw), tv);

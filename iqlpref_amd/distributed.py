@@ -55,9 +55,10 @@ def init_from_env(backend: Optional[str] = None, device: Optional[str] = None) -
     return dist.get_rank()
 
 
-def rank_seed(base_seed: int) -> int:
-    """Seed of this rank's run: base + rank (tr_sweeps/*.yaml grid their seeds)."""
-    return base_seed + (dist.get_rank() if dist.is_initialized() else 0)
+def rank_seed(base_seed: int, seeds_per_gpu: int = 1) -> int:
+    """First seed of this rank's runs: base + rank * seeds_per_gpu (tr_sweeps/*.yaml grid their
+    seeds; with K seeds per GPU rank r owns base + r K .. base + r K + K - 1)."""
+    return base_seed + (dist.get_rank() if dist.is_initialized() else 0) * int(seeds_per_gpu)
 
 
 def gather_metrics(record: Dict[str, float], device: Optional[str] = None) -> List[Dict[str, float]]:
@@ -71,6 +72,20 @@ def gather_metrics(record: Dict[str, float], device: Optional[str] = None) -> Li
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [dict(zip(FIELDS, o.tolist())) for o in out]
+
+
+def gather_metric_records(records: List[Dict[str, float]], device: Optional[str] = None) -> List[Dict[str, float]]:
+    """``gather_metrics`` for K records per rank (K seeds per GPU, the same K on every rank): ONE
+    all-gather of a [K, len(FIELDS)] block; every rank receives the K x world records, rank-major."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    rows = [[float(r.get(k, float("nan"))) for k in FIELDS[:-1]] + [float(rank)] for r in records]
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [dict(zip(FIELDS, row)) for row in rows]
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    t = torch.tensor(rows, dtype=torch.float64, device=dev)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [dict(zip(FIELDS, row)) for o in out for row in o.tolist()]
 
 
 def summarize(records: List[Dict[str, float]]) -> Dict[str, float]:

@@ -153,33 +153,8 @@ def build_dataset(config: TrainConfig, env, dataset=None) -> Dict[str, np.ndarra
     return d4rl.qlearning_dataset(env)
 
 
-def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[int] = None,
-          action_dim: Optional[int] = None, max_action: Optional[float] = None,
-          logger: Optional[Callable[[Dict[str, float], int], None]] = None,
-          evaluate: Optional[Callable] = None, precision: str = "bf16",
-          raw_dataset=None, host_prep: bool = False) -> ImplicitQLearning:
-    """ref:1393-1570.  ``dataset``: an already-built qlearning dataset (skips d4rl);
-    ``raw_dataset``: an env.get_dataset()-style dict handed to the relabel functions;
-    ``evaluate(actor, step) -> (scores, steps_to_goal)`` replaces eval_actor when gym is
-    not installed (None: evaluation is skipped); ``host_prep``: run the whole dataset preparation of
-    ref:1435-1456 in numpy on the host instead of the device kernels of iqlpref_amd.prep (both give
-    the reference's values to the last bit: the default path takes the state statistics from numpy
-    and does the reward normalisation, z-scoring and packing on the device)."""
-    # one process per GPU: under torchrun this rank owns cuda:<LOCAL_RANK>, and everything
-    # below (process group, buffer, trainer, metric all-gather) lives there
-    bound = D.local_device()
-    if bound is not None:
-        config.device = bound
-    rank = D.init_from_env(device=config.device)
-    if env is None and (state_dim is None or action_dim is None):
-        import gym
-        env = gym.make(config.env)
-    if state_dim is None:
-        state_dim = env.observation_space.shape[0]
-        action_dim = env.action_space.shape[0]
-    dataset = build_dataset(config, env, dataset if dataset is not None else raw_dataset) \
-        if (config.reward_model_path or dataset is None) else dataset
-
+def _prepare_replay(config: TrainConfig, dataset, state_dim, action_dim, host_prep: bool):
+    """ref:1435-1456: reward normalisation, state statistics, z-scoring, one device buffer."""
     replay_buffer = ReplayBuffer(state_dim, action_dim, config.buffer_size, config.device)
     if host_prep:  # ref:1435-1456 as written: numpy on the host, then one upload
         if config.normalize_reward:
@@ -198,17 +173,11 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
         state_mean, state_std = prep.prepare_replay(
             dataset, replay_buffer, env_name=config.env, normalize_reward=config.normalize_reward,
             normalize=config.normalize, eps=1e-3, stats="host")
-    if max_action is None:
-        max_action = float(env.action_space.high[0])
+    return replay_buffer, state_mean, state_std
 
-    if config.checkpoints_path is not None:
-        print(f"Checkpoints path: {config.checkpoints_path}")
-        os.makedirs(config.checkpoints_path, exist_ok=True)
-        import yaml
-        with open(os.path.join(config.checkpoints_path, "config.yaml"), "w") as f:
-            yaml.safe_dump(asdict(config), f)
 
-    seed = D.rank_seed(config.seed)  # one independent seed per rank / GPU
+def _build_trainer(config: TrainConfig, seed: int, state_dim, action_dim, max_action, precision) -> ImplicitQLearning:
+    """ref:1467-1520 for one seed: seeded initial weights, three Adam optimisers, the trainer."""
     set_seed(seed, None)
     if config.n_critics == 2:
         q_network = TwinQ(state_dim, action_dim).to(config.device)
@@ -230,54 +199,157 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
         max_steps=config.max_timesteps, precision=precision, seed=seed)
     if config.load_model != "":
         trainer.load_state_dict(torch.load(Path(config.load_model), weights_only=True))
+    return trainer
+
+
+def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[int] = None,
+          action_dim: Optional[int] = None, max_action: Optional[float] = None,
+          logger: Optional[Callable[[Dict[str, float], int], None]] = None,
+          evaluate: Optional[Callable] = None, precision: str = "bf16",
+          raw_dataset=None, host_prep: bool = False, seeds_per_gpu: int = 1):
+    """ref:1393-1570.  ``dataset``: an already-built qlearning dataset (skips d4rl);
+    ``raw_dataset``: an env.get_dataset()-style dict handed to the relabel functions;
+    ``evaluate(actor, step) -> (scores, steps_to_goal)`` replaces eval_actor when gym is
+    not installed (None: evaluation is skipped); ``host_prep``: run the whole dataset preparation of
+    ref:1435-1456 in numpy on the host instead of the device kernels of iqlpref_amd.prep (both give
+    the reference's values to the last bit: the default path takes the state statistics from numpy
+    and does the reward normalisation, z-scoring and packing on the device).
+
+    ``seeds_per_gpu`` = K > 1: K independent seeds of this config trained side by side on this
+    rank's GPU -- the reference launcher's AGENTS_PER_GPU (ensemble_sweeps/launch.sh:12,84-94: K
+    agents per GPU, each its own run).  Seed k of rank r is ``config.seed + r K + k``; every seed
+    has its own initial weights, Philox stream, optimiser state, logging window, evaluation seed
+    (ref:1547-1556: ``seed=config.seed`` of ITS run) and ``checkpoint_{t}.pt`` files (under
+    ``<checkpoints_path>/seed_<seed>/``), and is bit-identical to ``train()`` of that seed alone;
+    the steps of all K run as one ``SeedGroup`` (iqlpref_amd.multi).  With ``reward_model_root``
+    (iql_eval.py:143-146: the reward model is tied to the seed) every seed trains on its own
+    relabelled dataset, otherwise all share one device buffer.  Records of the loggers carry a
+    ``seed`` entry; the metric all-gather carries K x world records.  Returns the list of K
+    trainers (the single trainer when K = 1)."""
+    # one process per GPU: under torchrun this rank owns cuda:<LOCAL_RANK>, and everything
+    # below (process group, buffer, trainer, metric all-gather) lives there
+    bound = D.local_device()
+    if bound is not None:
+        config.device = bound
+    rank = D.init_from_env(device=config.device)
+    K = int(seeds_per_gpu)
+    if K < 1:
+        raise ValueError("seeds_per_gpu must be >= 1")
+    if env is None and (state_dim is None or action_dim is None):
+        import gym
+        env = gym.make(config.env)
+    if state_dim is None:
+        state_dim = env.observation_space.shape[0]
+        action_dim = env.action_space.shape[0]
+    seeds = [D.rank_seed(config.seed, K) + k for k in range(K)]  # one independent seed per rank / GPU and slot
+
+    # ---- datasets: one per seed when the reward model is tied to the seed, else one for all ----
+    source = dataset if dataset is not None else raw_dataset
+    per_seed_data = bool(config.reward_model_root) and K > 1
+    buffers, stats = [], []
+    for k in range(K if per_seed_data else 1):
+        cfg_k = config
+        if per_seed_data:
+            import copy
+            cfg_k = copy.copy(config)
+            cfg_k.reward_model_path = f"{config.reward_model_root}_{seeds[k]}"  # iql_eval.py:143-146
+        ds = build_dataset(cfg_k, env, source) if (cfg_k.reward_model_path or dataset is None) else dataset
+        if per_seed_data and ds is source:
+            ds = {key: np.array(val) for key, val in ds.items()}
+        buf, state_mean, state_std = _prepare_replay(config, ds, state_dim, action_dim, host_prep)
+        buffers.append(buf), stats.append((state_mean, state_std))
+    if not per_seed_data:
+        buffers, stats = buffers * K, stats * K
+    if max_action is None:
+        max_action = float(env.action_space.high[0])
+
+    ckpt_dirs = [None] * K
+    if config.checkpoints_path is not None:
+        print(f"Checkpoints path: {config.checkpoints_path}")
+        os.makedirs(config.checkpoints_path, exist_ok=True)
+        import yaml
+        with open(os.path.join(config.checkpoints_path, "config.yaml"), "w") as f:
+            yaml.safe_dump(asdict(config), f)
+        for k in range(K):
+            ckpt_dirs[k] = config.checkpoints_path if K == 1 else os.path.join(config.checkpoints_path, f"seed_{seeds[k]}")
+            os.makedirs(ckpt_dirs[k], exist_ok=True)
+
+    trainers = [_build_trainer(config, seeds[k], state_dim, action_dim, max_action, precision) for k in range(K)]
+    group = None
+    if K > 1:
+        from .multi import SeedGroup
+        group = SeedGroup(trainers)
 
     if logger is None:
         try:
             import wandb
             wandb.init(config=asdict(config), project=config.project, group=config.group, name=config.name)
-            logger = lambda d, step: wandb.log(d, step=step)
+            if K == 1:
+                logger = lambda d, step: wandb.log(d, step=step)
+            else:  # one process, K runs: the records of seed s go under "seed<s>/"
+                logger = lambda d, step: wandb.log({(f"seed{int(d['seed'])}/{n}" if "seed" in d else n): v
+                                                    for n, v in d.items() if n != "seed"}, step=step)
         except ImportError:
-            logger = lambda d, step: print(f"[{step}] " + " ".join(f"{k}={v:.5g}" for k, v in d.items()))
+            logger = lambda d, step: print(f"[{step}] " + " ".join(f"{n}={v:.5g}" for n, v in d.items()))
+    tag = (lambda rec, k: rec) if K == 1 else (lambda rec, k: dict(rec, seed=seeds[k]))
 
     total = int(config.max_timesteps)
     t = 0
     t_window = time.perf_counter()
+    windows: List[Optional[torch.Tensor]] = [None] * K
+    last: List[Dict[str, float]] = [{} for _ in range(K)]
     while t < total:
         # run to the next logging / evaluation boundary in one library call (ref:1533-1544)
         nxt = min(total, (t // config.log_freq + 1) * config.log_freq,
                   (t // config.eval_freq + 1) * config.eval_freq)
-        losses = trainer.train_steps(replay_buffer, nxt - t, config.batch_size)
-        window = losses if t % config.log_freq == 0 else torch.cat([window, losses])
+        if group is None:
+            losses = [trainers[0].train_steps(buffers[0], nxt - t, config.batch_size)]
+        else:
+            losses = group.train_steps(buffers, nxt - t, config.batch_size, return_losses=True)
+        for k in range(K):
+            windows[k] = losses[k] if t % config.log_freq == 0 else torch.cat([windows[k], losses[k]])
         t = nxt
         if t % config.log_freq == 0:
-            mean = window.mean(dim=0).tolist()  # the only host sync of the window
+            means = [w.mean(dim=0).tolist() for w in windows]  # the only host syncs of the window
             now = time.perf_counter()
-            rec = {"value_loss": mean[0], "q_loss": mean[1], "actor_loss": mean[2]}
-            logger(dict(rec), trainer.total_it)
-            last = dict(rec, steps_per_sec=window.shape[0] / max(now - t_window, 1e-9))
+            for k, mean in enumerate(means):
+                rec = {"value_loss": mean[0], "q_loss": mean[1], "actor_loss": mean[2]}
+                logger(tag(dict(rec), k), trainers[k].total_it)
+                last[k] = dict(rec, steps_per_sec=windows[k].shape[0] / max(now - t_window, 1e-9))
             t_window = now
         if t % config.eval_freq == 0:
-            eval_log: Dict[str, float] = {}
-            if evaluate is not None:
-                scores, steps_to_goal = evaluate(actor, t)
-            elif env is not None and hasattr(env, "spec"):
-                scores, steps_to_goal = eval_actor(config.env, actor, max_action, state_mean, state_std,
-                                                   config.device, config.n_episodes, config.seed)
-            else:
-                scores, steps_to_goal = None, []
-            if scores is not None:
-                eval_log["mean_score"] = float(np.mean(scores))
-                if "antmaze" in config.env.lower():
-                    eval_log["avg_steps_to_goal"] = float(np.mean(steps_to_goal)) if steps_to_goal else -1.0
-                logger(dict(eval_log), trainer.total_it)
-            if config.checkpoints_path is not None:
-                torch.save(trainer.state_dict(), os.path.join(config.checkpoints_path, f"checkpoint_{t - 1}.pt"))
+            if group is not None:
+                group.synchronize()
+            records = []
+            for k, trainer in enumerate(trainers):
+                eval_log: Dict[str, float] = {}
+                actor = trainer.actor
+                if evaluate is not None:
+                    scores, steps_to_goal = evaluate(actor, t)
+                elif env is not None and hasattr(env, "spec"):
+                    # the evaluation seed of a run is the run's own seed (ref:1547-1556)
+                    scores, steps_to_goal = eval_actor(config.env, actor, max_action, stats[k][0], stats[k][1],
+                                                       config.device, config.n_episodes, seeds[k])
+                else:
+                    scores, steps_to_goal = None, []
+                if scores is not None:
+                    eval_log["mean_score"] = float(np.mean(scores))
+                    if "antmaze" in config.env.lower():
+                        eval_log["avg_steps_to_goal"] = float(np.mean(steps_to_goal)) if steps_to_goal else -1.0
+                    logger(tag(dict(eval_log), k), trainer.total_it)
+                if ckpt_dirs[k] is not None:
+                    torch.save(trainer.state_dict(), os.path.join(ckpt_dirs[k], f"checkpoint_{t - 1}.pt"))
+                records.append(dict(last[k] if t >= config.log_freq else {}, seed=seeds[k],
+                                    total_it=trainer.total_it, **eval_log))
             # end-of-eval metric exchange across the per-GPU seeds (the path's only collective)
-            recs = D.gather_metrics(dict(last if t >= config.log_freq else {}, seed=seed,
-                                         total_it=trainer.total_it, **eval_log), device=config.device)
+            recs = D.gather_metric_records(records, device=config.device)
             if rank == 0 and len(recs) > 1:
-                logger(D.summarize(recs), trainer.total_it)
-    return trainer
+                logger(D.summarize(recs), trainers[0].total_it)
+    if group is not None:
+        group.synchronize()
+        group.close()
+        return trainers
+    return trainers[0]
 
 
 def main(argv=None):
@@ -286,6 +358,9 @@ def main(argv=None):
     from .iql import load_config
     ap = argparse.ArgumentParser()
     ap.add_argument("--config_path", default=None)
+    ap.add_argument("--seeds_per_gpu", type=int, default=int(os.environ.get("AGENTS_PER_GPU", "1")),
+                    help="independent seeds trained side by side on each GPU "
+                         "(ensemble_sweeps/launch.sh:12 AGENTS_PER_GPU)")
     args, rest = ap.parse_known_args(argv)
     over = {}
     it = iter(rest)
@@ -297,7 +372,7 @@ def main(argv=None):
             else:
                 v = next(it)
             over[k] = v
-    train(load_config(args.config_path, **over))
+    train(load_config(args.config_path, **over), seeds_per_gpu=args.seeds_per_gpu)
 
 
 if __name__ == "__main__":

@@ -28,6 +28,15 @@ assert s["n_seeds"] == 2 and s["steps_per_sec_total"] == 2000.0 and s["mean_scor
 assert abs(s["mean_score_std"] - 5.0) < 1e-12
 import math
 assert math.isnan(recs[0]["avg_steps_to_goal"])
+# K = 2 seeds per GPU: rank r owns seeds base + 2 r, base + 2 r + 1; one all-gather carries K x world records
+first = D.rank_seed(10, 2)
+assert first == 10 + 2 * rank
+recs = D.gather_metric_records([{"seed": first + k, "total_it": 50, "q_loss": float(first + k),
+                                 "steps_per_sec": 500.0} for k in range(2)], device="cpu")
+assert [r["seed"] for r in recs] == [10.0, 11.0, 12.0, 13.0], recs
+assert [r["rank"] for r in recs] == [0.0, 0.0, 1.0, 1.0]
+assert [r["q_loss"] for r in recs] == [10.0, 11.0, 12.0, 13.0]
+assert D.summarize(recs)["steps_per_sec_total"] == 2000.0 and D.summarize(recs)["n_seeds"] == 4
 dist.barrier()
 dist.destroy_process_group()
 print("ok", rank)
@@ -56,6 +65,8 @@ def test_single_process_gather_is_identity():
     from iqlpref_amd import distributed as D
     recs = D.gather_metrics({"seed": 3, "total_it": 7, "q_loss": 1.5})
     assert len(recs) == 1 and recs[0]["seed"] == 3.0 and recs[0]["q_loss"] == 1.5 and recs[0]["rank"] == 0.0
+    recs = D.gather_metric_records([{"seed": 3, "q_loss": 1.5}, {"seed": 4, "q_loss": 2.5}])
+    assert [r["seed"] for r in recs] == [3.0, 4.0] and recs[1]["q_loss"] == 2.5 and D.rank_seed(3, 8) == 3
 
 
 def test_rank_to_gpu_mapping():

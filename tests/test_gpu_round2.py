@@ -84,7 +84,7 @@ def test_config3_pipeline_pt_relabel_then_train(gh, mode):
         out = o.train(orc.gather_batch(data, philox.sample_indices(21, t, B, n)), km)
         w = np.array([out["value_loss"], out["q_loss"], out["actor_loss"]])
         worst = max(worst, float(np.max(np.abs(got[t] - w) / np.abs(w))))
-        np.testing.assert_allclose(got[t], w, rtol=2e-4 if mode == "fp32" else 2e-2, err_msg=f"step {t}")
+        np.testing.assert_allclose(got[t], w, rtol=2e-4 if mode == "fp32" else 1e-2, err_msg=f"step {t}")
     _diag(f"config3 {mode}: worst relative loss error over {K} steps {worst:.3e}")
     assert np.isfinite(got).all() and got[-1, 1] < got[0, 1]  # the critics learn the relabelled reward
 
@@ -255,3 +255,33 @@ def test_checkpoint_read_by_the_reference_matches_our_actor():
     st = tr.actor_optimizer.state[a2.log_std]
     assert float(st["step"]) == 25 and torch.equal(st["exp_avg"].cpu(),
                                                    ck["actor_optimizer"]["state"][0]["exp_avg"])
+
+
+# ----------------------------------------------------------------------------- #
+# The multi-rank launcher of bench.py, end to end on ONE GPU: two rank processes (fresh
+# interpreters, started before this process has touched the GPU in them) sharing cuda:0, the
+# collectives over gloo (IQL_BENCH_BACKEND=gloo; the driver's SCALE runs use the default, RCCL).
+# ----------------------------------------------------------------------------- #
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR",
+                                                              "MASTER_PORT")}
+    env["IQL_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout  # rank 0 prints ONE JSON line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 20 and rec["warmup"] == 5 and rec["scaling"] == "weak"
+    assert rec["metric"] == "iql_grad_steps_per_sec" and rec["unit"] == "steps/s"
+    ranks = rec["ranks"]
+    assert [r["rank"] for r in ranks] == [0.0, 1.0] and ranks[0]["seed"] != ranks[1]["seed"]
+    assert all(np.isfinite([r["value_loss"], r["q_loss"], r["actor_loss"]]).all() for r in ranks)
+    assert ranks[0]["q_loss"] != ranks[1]["q_loss"]  # two different runs
+    # whole-job value = 2 x K steps / the slower rank's block time
+    assert abs(rec["value"] - 2 * 20 / (rec["ms_per_step"] * 20 / 1e3)) / rec["value"] < 1e-9
+    assert rec["value"] > 2_000  # two ranks sharing one GPU still run thousands of steps/s

@@ -80,12 +80,20 @@ def _drop_tensor(d, hyper, gh):
 TOL = {
     # (loss rtol vs oracle, loss rtol vs reference golden, param atol vs oracle, vs golden)
     "fp32": dict(lo=2e-5, lg=2e-5, po=2e-6, pg=2e-6),
-    "bf16": dict(lo=5e-3, lg=2e-2, po=2e-3, pg=2e-3),
+    # bf16: an absolute parameter bound of the size of the K-step movement (K * lr = 3e-3) would pin
+    # nothing; what pins the bf16 update is the MOVEMENT final - initial of every tensor against the
+    # oracle's / the reference's, as a relative L2 error (BF16_DELTA_*), and the Adam moments below.
+    "bf16": dict(lo=5e-3, lg=2e-2),
 }
-# bf16 mode: the absolute bound above (2e-3) is about the size of the whole K-step movement
-# (K * lr = 3e-3), so by itself it pins nothing.  What pins the bf16 update is the MOVEMENT
-# final - initial of every tensor against the oracle's / the reference's, as a relative L2 error.
-BF16_DELTA_REL = 0.05
+# Bounds = ~5 x the largest figure measured on an MI355X (IQL_TEST_DIAG; gpurun_out/r3v/diag.txt and
+# this round's run): movement vs the oracle <= 0.0004, vs the reference's golden <= 0.0016.
+BF16_DELTA_ORACLE = 0.005
+BF16_DELTA_GOLDEN = 0.01
+# Adam moments, largest error relative to the tensor's largest entry: (fp32, bf16) -- the bf16 figures
+# are ~5 x the measured ones; at H = 256 one relu'(z) falling the other way under another summation
+# order moves isolated entries by a sample's share (see tests/test_oracle_golden.py), so there the
+# bound holds for all but 0.5 % of a tensor's entries and a looser one for every entry.
+MOMENT_TOL = {"fp32": (1e-4, 1e-4), "bf16": (5e-3, 1e-2)}
 
 
 def _delta_rel(final, init, want_final):
@@ -94,8 +102,10 @@ def _delta_rel(final, init, want_final):
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
-@pytest.mark.parametrize("name", helpers.TRAJ)
+@pytest.mark.parametrize("name", helpers.TRAJ + helpers.TRAJ_BIG)
 def test_trajectory_parity(gh, name, mode):
+    """K steps with the reference's injected indices (and dropout masks) vs the oracle AND the
+    reference's own trajectory.  TRAJ_BIG = BASELINE configs 1 / 3 and config 5's batch at H = 256."""
     d, hyper, data, nets = helpers.load_traj(name, mode)
     K, B = hyper["k_steps"], hyper["batch"]
     tr = gh.make_trainer(hyper, nets, mode)
@@ -109,41 +119,59 @@ def test_trajectory_parity(gh, name, mode):
         out = o.train(orc.gather_batch(data, d["indices"][t]), helpers.keep_masks(d, hyper, t))
         want[t] = [out["value_loss"], out["q_loss"], out["actor_loss"]]
     tol = TOL[mode]
+    _diag(f"{name} {mode} loss rel vs oracle {np.abs(losses / want - 1).max():.2e} vs golden "
+          f"{np.abs(losses / d['losses'] - 1).max():.2e}")
     np.testing.assert_allclose(losses, want, rtol=tol["lo"], err_msg="vs oracle")
     np.testing.assert_allclose(losses, d["losses"], rtol=tol["lg"], err_msg="vs reference golden")
     assert tr.total_it == K
     assert abs(tr.actor_optimizer.param_groups[0]["lr"] - float(d["final_actor_lr"])) < 1e-12
+    big = hyper["hidden"] >= 256
     for net, mod, opar in (("qf", tr.qf, o.qf), ("vf", tr.vf, o.vf), ("actor", tr.actor, o.actor),
                            ("q_target", tr.q_target, o.q_target)):
         got = gh.module_params(mod)
         init = nets[{"qf": 0, "vf": 1, "actor": 2, "q_target": 0}[net]]
         for k, v in got.items():
-            np.testing.assert_allclose(v, opar[k], atol=tol["po"], rtol=0, err_msg=f"{net}/{k} vs oracle")
             wantg, gotg = helpers.golden_param(d, f"final/{net}/{k}", v)
             assert wantg is not None
-            np.testing.assert_allclose(gotg, wantg.reshape(gotg.shape), atol=tol["pg"], rtol=0,
-                                       err_msg=f"{net}/{k} vs golden")
-            if mode == "bf16":
-                rel = _delta_rel(v, np.asarray(init[k]), opar[k])
-                _diag(f"{name} {net}/{k} delta rel vs oracle {rel:.4f}")
-                assert rel < BF16_DELTA_REL, f"{net}/{k}: movement differs from the oracle's by {rel:.3f} (rel. L2)"
-                if wantg.size == v.size:  # full tensors only (large ones are stored strided)
-                    relg = _delta_rel(v, np.asarray(init[k]), wantg.reshape(v.shape))
-                    _diag(f"{name} {net}/{k} delta rel vs golden {relg:.4f}")
-                    assert relg < 2 * BF16_DELTA_REL, f"{net}/{k}: movement vs the reference {relg:.3f}"
+            wantg = wantg.reshape(gotg.shape)
+            if mode == "fp32" and not big:
+                np.testing.assert_allclose(v, opar[k], atol=tol["po"], rtol=0, err_msg=f"{net}/{k} vs oracle")
+                np.testing.assert_allclose(gotg, wantg, atol=tol["pg"], rtol=0, err_msg=f"{net}/{k} vs golden")
+                continue
+            if mode == "fp32":
+                # H = 256: Adam's first steps are sign-like (lr g / (|g| + eps)), so summation-order
+                # noise on an eps-sized gradient entry shows up in its parameter (measured: 1 of 65,536
+                # entries 2.8e-6 away): all but 1e-4 of a tensor within the bound, none beyond 5 x it
+                for what, a, b in (("oracle", v, opar[k]), ("golden", gotg, wantg)):
+                    diff = np.abs(a - b)
+                    _diag(f"{name} {net}/{k} fp32 max abs vs {what} {diff.max():.2e}")
+                    assert (diff > tol["po"]).mean() < 1e-4 and diff.max() < 5 * tol["po"], (net, k, what, diff.max())
+                continue
+            rel = _delta_rel(v, np.asarray(init[k]), opar[k])
+            _diag(f"{name} {net}/{k} delta rel vs oracle {rel:.4f}")
+            assert rel < BF16_DELTA_ORACLE, f"{net}/{k}: movement differs from the oracle's by {rel:.4f} (rel. L2)"
+            # (large tensors are stored as every 37th element: the movement of that sample)
+            initg = np.asarray(init[k]).reshape(-1)[::37] if wantg.size != v.size else np.asarray(init[k])
+            relg = _delta_rel(gotg, initg.reshape(gotg.shape), wantg)
+            _diag(f"{name} {net}/{k} delta rel vs golden {relg:.4f}")
+            assert relg < BF16_DELTA_GOLDEN, f"{net}/{k}: movement vs the reference {relg:.4f}"
     # Adam moments (exp_avg = EMA of the gradients: pins the backward pass)
+    t1, t2 = MOMENT_TOL[mode]
     for which, opt, mod in (("q", tr.q_optimizer, tr.qf), ("v", tr.v_optimizer, tr.vf),
                             ("actor", tr.actor_optimizer, tr.actor)):
         for (pname, p) in mod.named_parameters():
             st = opt.state[p]
             assert float(st["step"]) == K
-            m_want = o.m[which][pname]
-            scale = np.abs(m_want).max() + 1e-30
-            err = np.abs(st["exp_avg"].cpu().numpy() - m_want).max() / scale
-            assert err < (1e-4 if mode == "fp32" else 2e-2), (which, pname, err)
-            v_want = o.v2[which][pname]
-            errv = np.abs(st["exp_avg_sq"].cpu().numpy() - v_want).max() / (np.abs(v_want).max() + 1e-30)
-            assert errv < (1e-4 if mode == "fp32" else 4e-2), (which, pname, errv)
+            m_want, v_want = o.m[which][pname], o.v2[which][pname]
+            err = np.abs(st["exp_avg"].cpu().numpy() - m_want) / (np.abs(m_want).max() + 1e-30)
+            errv = np.abs(st["exp_avg_sq"].cpu().numpy() - v_want) / (np.abs(v_want).max() + 1e-30)
+            _diag(f"{name} {mode} moments {which}/{pname}: exp_avg {err.max():.2e} exp_avg_sq {errv.max():.2e} "
+                  f"outliers {(err > t1).mean():.1e} {(errv > t2).mean():.1e}")
+            if mode == "bf16" and big:
+                assert (err > t1).mean() < 5e-3 and err.max() < 0.25, (which, pname, err.max())
+                assert (errv > t2).mean() < 5e-3 and errv.max() < 0.25, (which, pname, errv.max())
+            else:
+                assert err.max() < t1 and errv.max() < t2, (which, pname, err.max(), errv.max())
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])

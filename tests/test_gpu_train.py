@@ -110,3 +110,91 @@ def test_build_dataset_branches(tmp_path):
     for k in want:
         np.testing.assert_allclose(np.asarray(out[k], np.float32), np.asarray(want[k], np.float32),
                                    rtol=5e-3, atol=5e-3)
+
+
+def test_seeds_per_gpu_equals_solo_runs_bit_for_bit(tmp_path):
+    """ensemble_sweeps/launch.sh:12,84-94 (AGENTS_PER_GPU agents per GPU, each its own run):
+    train(cfg, seeds_per_gpu=3) = three solo train() runs of seeds s, s+1, s+2 -- every logged loss
+    window, every evaluation call (own actor, own seed), every checkpoint tensor."""
+    import iqlpref_amd as ia
+    S, A, N, B = 29, 8, 3000, 64
+    data = synth(N, S, A)
+
+    def run(seed, k_seeds, sub):
+        cfg = ia.TrainConfig(env="antmaze-medium-diverse-v2", max_timesteps=60, log_freq=10, eval_freq=30,
+                             batch_size=B, normalize_reward=1, beta=10.0, iql_tau=0.9, seed=seed, device=DEV,
+                             buffer_size=10_000_000, checkpoints_path=str(tmp_path / sub))
+        logs, evals = [], []
+
+        def evaluate(actor, t):  # a value that depends on the actor handed in
+            w = actor.net.linears()[2].weight
+            evals.append((t, float(w.double().sum())))
+            return np.array([float(w[0, 0]), 1.0]), [t]
+        out = ia.train(cfg, dataset={k: v.copy() for k, v in data.items()}, state_dim=S, action_dim=A,
+                       max_action=1.0, logger=lambda d, step: logs.append((step, dict(d))), evaluate=evaluate,
+                       precision="bf16", seeds_per_gpu=k_seeds)
+        return cfg, out, logs, evals
+
+    cfg_g, trainers, logs_g, evals_g = run(7, 3, "group")
+    assert isinstance(trainers, list) and [t._seed for t in trainers] == [7, 8, 9]
+    assert all(t.total_it == 60 for t in trainers)
+    assert [e[0] for e in evals_g] == [30, 30, 30, 60, 60, 60]
+    for k in range(3):
+        cfg_s, tr, logs_s, evals_s = run(7 + k, 1, f"solo{k}")
+        mine = [(st, {n: v for n, v in d.items() if n != "seed"}) for st, d in logs_g if d.get("seed") == 7 + k]
+        assert len(mine) == len(logs_s) == 6 + 2 and mine == logs_s  # 6 loss windows + 2 evaluations, equal floats
+        assert [e for i, e in enumerate(evals_g) if i % 3 == k] == evals_s
+        assert torch.equal(tr._params, trainers[k]._params) and torch.equal(tr._target, trainers[k]._target)
+        for step in (29, 59):
+            a = torch.load(os.path.join(cfg_g.checkpoints_path, f"seed_{7 + k}", f"checkpoint_{step}.pt"), weights_only=True)
+            b = torch.load(os.path.join(cfg_s.checkpoints_path, f"checkpoint_{step}.pt"), weights_only=True)
+            assert a["total_it"] == b["total_it"] == step + 1
+            for net in ("qf", "vf", "actor"):
+                for name in a[net]:
+                    assert torch.equal(a[net][name], b[net][name]), (net, name)
+            for opt in ("q_optimizer", "v_optimizer", "actor_optimizer"):
+                for i, st in a[opt]["state"].items():
+                    assert torch.equal(st["exp_avg"], b[opt]["state"][i]["exp_avg"])
+                    assert torch.equal(st["exp_avg_sq"], b[opt]["state"][i]["exp_avg_sq"])
+            assert a["actor_lr_schedule"]["last_epoch"] == b["actor_lr_schedule"]["last_epoch"]
+    # different seeds did train differently
+    assert not torch.equal(trainers[0]._params, trainers[1]._params)
+
+
+def test_seed_tied_reward_models_give_every_seed_its_own_dataset(tmp_path):
+    """iql_eval.py:143-146: reward_model_path = f"{root}_{seed}": with K seeds per GPU seed s trains
+    on the dataset relabelled by ITS reward model."""
+    import iqlpref_amd as ia
+    S, A, N = 6, 3, 400
+    rng = np.random.default_rng(1)
+    raw = {"observations": rng.standard_normal((N, S)).astype(np.float32),
+           "actions": rng.uniform(-1, 1, (N, A)).astype(np.float32),
+           "rewards": np.zeros(N, np.float32), "terminals": rng.uniform(size=N) < 0.02,
+           "timeouts": np.zeros(N, bool)}
+    raw["timeouts"][[99, 199, 299]] = True
+
+    class Env:
+        _max_episode_steps = 100
+
+    for seed in (3, 4):
+        mr = tmp_path / f"mr_{seed}"
+        mr.mkdir()
+        (mr / "config.yaml").write_text("activations: relu\n")
+        w = [np.random.default_rng(seed).standard_normal(s).astype(np.float32) * 0.4
+             for s in ((S + A, 16), (16,), (16, 16), (16,), (16, 1), (1,))]
+        torch.save({"net": {"layers.0.W": torch.from_numpy(w[0]), "layers.0.b": torch.from_numpy(w[1]),
+                            "layers.linear_1.W": torch.from_numpy(w[2]), "layers.linear_1.b": torch.from_numpy(w[3]),
+                            "output.W": torch.from_numpy(w[4]), "output.b": torch.from_numpy(w[5])}},
+                   mr / "best_model.pt")
+
+    def run(seed, k):
+        cfg = ia.TrainConfig(env="pen-human-v1", reward_model_root=str(tmp_path / "mr"), query_length=1, seed=seed,
+                             max_timesteps=12, log_freq=6, eval_freq=12, batch_size=32, device=DEV)
+        assert cfg.reward_model_path == str(tmp_path / "mr") + f"_{seed}"
+        return ia.train(cfg, env=Env(), raw_dataset=dict(raw), state_dim=S, action_dim=A, max_action=1.0,
+                        logger=lambda d, step: None, precision="fp32", seeds_per_gpu=k)
+
+    both = run(3, 2)
+    for k, tr in enumerate(both):
+        solo = run(3 + k, 1)
+        assert torch.equal(solo._params, tr._params), k
