@@ -60,6 +60,17 @@ __device__ __forceinline__ void stg16_wt(void *p, float4 v) {
                "v"(__builtin_bit_cast(u32x4_t, v))
                : "memory");
 }
+// the same with a uniform (scalar-register) base and a 32-bit per-lane byte offset: no 64-bit
+// per-lane address is ever formed (each would hold two registers from the first use to the store)
+__device__ __forceinline__ void stg16_wt(const void *sbase, uint32_t voff, float4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(__builtin_bit_cast(u32x4_t, v)),
+               "s"(sbase)
+               : "memory");
+}
+__device__ __forceinline__ void stg16(const void *sbase, uint32_t voff, float4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(__builtin_bit_cast(u32x4_t, v)), "s"(sbase)
+               : "memory");
+}
 __device__ __forceinline__ void stg8(void *p, uint2 v) {
   *(u32x2_t IQL_AS1 *)p = __builtin_bit_cast(u32x2_t, v);
 }

@@ -1155,16 +1155,25 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
 // Polyak update of a target weight t towards the new weight p.  Two forms, different rounding:
 //   offline/iql.py:127-129        tp.lerp_(sp, tau)                       t + tau (p - t)
 //   custom_offline/iql.py:85-87   copy_((1 - tau) * tp + tau * sp)        (1 - tau) t + tau p
+// The roundings of these two functions are spelled out and contraction is off inside them: with
+// the default -ffp-contract=fast the compiler chose DIFFERENT fused forms for the same source line
+// in two call sites (v b2 + ((1 - b2) g) g became fma(b2, v, ((1 - b2) g) g) in one kernel path and
+// fma((1 - b2) g, g, v b2) in another: one ulp apart), and every code path that updates a parameter
+// must give the same bits (seeds in a group launch == the seed alone).
 __device__ __forceinline__ float polyak(const TrainerDesc &D, float t, float p) {
-  return D.polyak_convex ? D.one_m_tau * t + D.tau * p : t + D.tau * (p - t);
+#pragma clang fp contract(off)
+  // convex form: two rounded products and a sum, as the tensor expression (1 - tau) * tp + tau * sp
+  // evaluates; lerp form: one fused multiply-add over the rounded difference (ATen's lerp kernel)
+  return D.polyak_convex ? (D.one_m_tau * t) + (D.tau * p) : __builtin_fmaf(D.tau, p - t, t);
 }
 
 __device__ __forceinline__ void adam_apply(float &p, float &m, float &v, float g, const AdamCoef &c,
                                            float neg_step) {
-  m = m + (g - m) * c.one_m_b1;                 // exp_avg.lerp_(grad, 1 - beta1)
-  v = v * c.b2 + (c.one_m_b2 * g) * g;          // mul_(beta2).addcmul_(g, g, 1 - beta2)
+#pragma clang fp contract(off)
+  m = __builtin_fmaf(g - m, c.one_m_b1, m);                 // exp_avg.lerp_(grad, 1 - beta1)
+  v = __builtin_fmaf(c.b2, v, (c.one_m_b2 * g) * g);        // mul_(beta2).addcmul_(g, g, 1 - beta2)
   const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
-  p = p + neg_step * (m / denom);               // addcdiv_(exp_avg, denom, -step_size)
+  p = __builtin_fmaf(neg_step, m / denom, p);               // addcdiv_(exp_avg, denom, -step_size)
 }
 
 // beta^t by binary exponentiation (t <= 2^31): a few ulp, ~60 double multiplies
@@ -1199,16 +1208,27 @@ __device__ __forceinline__ void write_adam_coef(const TrainerDesc &D, const DevA
 }
 
 // The fp32 optimiser state (masters, moments, target) a tile writes is next read one step later by
-// the same tile's successor: IQL_WT_STATE (A/B build) stores it write-through so that the kernel
-// leaves nothing of it dirty for the release at the kernel boundary.
+// the same tile's successor: it is stored write-through (sc0 sc1), so the bytes leave while the
+// kernel still runs and nothing of them is dirty for the release at the kernel boundary (the
+// boundary behind k_update costs + dirty bytes / 6 TB/s, MI355X_MICROARCH.md "boundary").  A/B on
+// one box (round 3, r4b): one seed 63.4k -> 64.9k steps/s (k_update 5.8 -> 5.4 us in the launch
+// tiling), 8 seeds per launch 171.2k -> 172.4k.  (`nt` stores, tried in round 2, are not
+// write-through: no effect.)  -DIQL_WT_STATE=0 builds the plain-store variant.
 #ifndef IQL_WT_STATE
-#define IQL_WT_STATE 0
+#define IQL_WT_STATE 1
 #endif
 __device__ __forceinline__ void state_store(float *p, float4 v) {
 #if IQL_WT_STATE
   stg16_wt(p, v);
 #else
   stg16(p, v);
+#endif
+}
+__device__ __forceinline__ void state_store(const void *sbase, uint32_t voff, float4 v) {  // uniform base + lane offset
+#if IQL_WT_STATE
+  stg16_wt(sbase, voff, v);
+#else
+  stg16(sbase, voff, v);
 #endif
 }
 
@@ -1547,13 +1567,20 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   // LDS hand-over to the row-ordered Adam pass) then start as soon as the fragments are in, while
   // the state is still streaming (+0.8 % measured).  First chunk straight-line: a loop
   // pre-header would drain every pending load.
+  // (addresses as uniform base + ONE 32-bit lane offset: global_load ... v_off, s[base:base+1];
+  // a 64-bit per-lane address per fragment costs two registers each while the loads are issued)
+  const uint32_t lane16 = (uint32_t)lane * 16u;
   auto load_frags = [&](const int k0, uint4(&xf)[UKC], uint4(&zf)[UKC][UNB]) {
+    const char *const xb = reinterpret_cast<const char *>(Xsrc) + (size_t)((ib >> 4) * nk) * 1024;
+    const char *zb[UNB];
+#pragma unroll
+    for (int b = 0; b < UNB; ++b) zb[b] = reinterpret_cast<const char *>(Zsrc) + (size_t)(ot[b] * nk) * 1024;
 #pragma unroll
     for (int ks = 0; ks < UKC; ++ks) {
-      const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
-      xf[ks] = ldg16(Xsrc + frag_off<P>(ib >> 4, kk, nk, lane));
+      const int kk = k0 + ks < nk ? k0 + ks : nk - 1;  // (one fragment = 64 lanes x 16 B = 1 KiB, both precisions)
+      xf[ks] = ldg16(xb + (size_t)kk * 1024 + lane16);
 #pragma unroll
-      for (int b = 0; b < UNB; ++b) zf[ks][b] = ldg16(Zsrc + frag_off<P>(ot[b], kk, nk, lane));
+      for (int b = 0; b < UNB; ++b) zf[ks][b] = ldg16(zb[b] + (size_t)kk * 1024 + lane16);
     }
   };
   auto mma_frags = [&](const int k0, const uint4(&xf)[UKC], const uint4(&zf)[UKC][UNB]) {

@@ -243,8 +243,12 @@ class ReplayBuffer:
         self._generation = _buffer_generation[0]
 
     def view(self) -> _lib.ReplayView:
-        return _lib.ReplayView(ptr(self._rows), min(self._size, self._pointer), self._stride,
-                               self._state_dim, self._action_dim, self._generation)
+        key = (self._rows.data_ptr(), self._size, self._pointer, self._generation)
+        if getattr(self, "_view_key", None) != key:  # (the struct is rebuilt only when something changed)
+            self._view = _lib.ReplayView(ptr(self._rows), min(self._size, self._pointer), self._stride,
+                                         self._state_dim, self._action_dim, self._generation)
+            self._view_key = key
+        return self._view
 
     def sample(self, batch_size: int, indices: Optional[torch.Tensor] = None) -> TensorBatch:
         """ref:211-221.  Indices are drawn on device (Philox keyed by the torch seed
@@ -623,16 +627,27 @@ class ImplicitQLearning:
                 view.copy_(p.data)
                 p.data = view
 
-    def _bind_optimizer_state(self):
+    def _bind_optimizer_state(self, rebuild: bool = False):
         """Adam moments live in the arenas; expose them through optimizer.state so
-        ``optimizer.state_dict()`` stays what torch.optim.Adam would write."""
-        for p, o in self._views:
-            for opt in (self.q_optimizer, self.v_optimizer, self.actor_optimizer):
-                if any(p is q for q in opt.param_groups[0]["params"]):
-                    st = opt.state[p]
-                    st["step"] = torch.tensor(float(self.total_it))
-                    st["exp_avg"] = self._exp_avg[o:o + p.numel()].view(p.shape)
-                    st["exp_avg_sq"] = self._exp_avg_sq[o:o + p.numel()].view(p.shape)
+        ``optimizer.state_dict()`` stays what torch.optim.Adam would write.  The views are made
+        once (and again after ``load_state_dict``, which replaces the state tensors); afterwards a
+        call only moves the step counters."""
+        steps = getattr(self, "_step_tensors", None)
+        if steps is None or rebuild:
+            steps = []
+            for p, o in self._views:
+                for opt in (self.q_optimizer, self.v_optimizer, self.actor_optimizer):
+                    if any(p is q for q in opt.param_groups[0]["params"]):
+                        st = opt.state[p]
+                        st["step"] = torch.tensor(float(self.total_it))
+                        st["exp_avg"] = self._exp_avg[o:o + p.numel()].view(p.shape)
+                        st["exp_avg_sq"] = self._exp_avg_sq[o:o + p.numel()].view(p.shape)
+                        steps.append(st["step"])
+            self._step_tensors = steps
+            return
+        t = float(self.total_it)
+        for st in steps:
+            st.fill_(t)
 
     def _ensure_handle(self, batch_size: int):
         if self._handle is not None and self._handle_batch == batch_size:
@@ -682,9 +697,11 @@ class ImplicitQLearning:
         self._bind_optimizer_state()
 
     def _refresh_lrs(self):
-        g = lambda opt: float(opt.param_groups[0]["lr"])
-        check(self._lib.iqlhip_trainer_set_lr(self._handle, g(self.q_optimizer), g(self.v_optimizer),
-                                              float(self.actor_lr_schedule.base_lrs[0])))
+        lrs = (self._handle.value, float(self.q_optimizer.param_groups[0]["lr"]),
+               float(self.v_optimizer.param_groups[0]["lr"]), float(self.actor_lr_schedule.base_lrs[0]))
+        if lrs != getattr(self, "_lrs_sent", None):
+            check(self._lib.iqlhip_trainer_set_lr(self._handle, *lrs[1:]))
+            self._lrs_sent = lrs
 
     # -- the step ----------------------------------------------------------- #
     def train(self, batch: TensorBatch, dropout_keep: Optional[torch.Tensor] = None) -> Dict[str, float]:
@@ -722,9 +739,13 @@ class ImplicitQLearning:
             dropout_keep = dropout_keep.to(torch.uint8).contiguous()
         v = replay_buffer.view()
         unroll = self._graph_unroll if graph_unroll is None else graph_unroll
-        with torch.cuda.device(self._dev):
+        if torch.cuda.current_device() == (self._dev.index or 0):  # (the context manager costs ~5 us a call)
             check(self._lib.iqlhip_train_steps(self._handle, C.byref(v), n_steps, ptr(indices),
                                                ptr(dropout_keep), ptr(losses), unroll, stream_ptr()))
+        else:
+            with torch.cuda.device(self._dev):
+                check(self._lib.iqlhip_train_steps(self._handle, C.byref(v), n_steps, ptr(indices),
+                                                   ptr(dropout_keep), ptr(losses), unroll, stream_ptr()))
         self._after_steps(n_steps)
         return losses
 
@@ -767,7 +788,7 @@ class ImplicitQLearning:
                         self._exp_avg[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
                         self._exp_avg_sq[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
             self._target.copy_(self._params[:self._n_target])  # ref:679 deepcopy(qf)
-        self._bind_optimizer_state()
+        self._bind_optimizer_state(rebuild=True)
         if self._handle is not None:
             with torch.cuda.device(self._dev):
                 check(self._lib.iqlhip_trainer_set_step(self._handle, self.total_it))

@@ -115,9 +115,11 @@ def test_trajectory_parity(gh, name, mode):
                             graph_unroll=0).cpu().numpy()
     o = helpers.make_oracle(hyper, nets, mode)
     want = np.zeros((K, 3))
+    margin = np.inf  # closest any pre-activation / advantage of any step came to a kink
     for t in range(K):
         out = o.train(orc.gather_batch(data, d["indices"][t]), helpers.keep_masks(d, hyper, t))
         want[t] = [out["value_loss"], out["q_loss"], out["actor_loss"]]
+        margin = min(margin, min(o.last_margin.values()))
     tol = TOL[mode]
     _diag(f"{name} {mode} loss rel vs oracle {np.abs(losses / want - 1).max():.2e} vs golden "
           f"{np.abs(losses / d['losses'] - 1).max():.2e}")
@@ -141,11 +143,19 @@ def test_trajectory_parity(gh, name, mode):
             if mode == "fp32":
                 # H = 256: Adam's first steps are sign-like (lr g / (|g| + eps)), so summation-order
                 # noise on an eps-sized gradient entry shows up in its parameter (measured: 1 of 65,536
-                # entries 2.8e-6 away): all but 1e-4 of a tensor within the bound, none beyond 5 x it
+                # entries of a hidden layer, 10 of 4,352 of a first layer, <= 2.8e-6 away): all but 1 %
+                # of a tensor within the bound, none beyond 5 x it
+                # ... unless a pre-activation came within fp32 noise of a ReLU kink (the oracle reports the
+                # margin): two fp32 implementations can then fall on different sides of relu'(z) for ONE
+                # (sample, unit) pair in ONE step, which moves that unit's row of gradients by the sample's
+                # share and, through the sign-like steps, its parameters by up to lr per step (measured on
+                # traj_cheetah_h256: 140 of 65,536 entries of one matrix, <= 3.5e-5)
+                cap = 5 * tol["po"] if margin > 1e-5 else K * 3e-4 * 1.01
                 for what, a, b in (("oracle", v, opar[k]), ("golden", gotg, wantg)):
                     diff = np.abs(a - b)
-                    _diag(f"{name} {net}/{k} fp32 max abs vs {what} {diff.max():.2e}")
-                    assert (diff > tol["po"]).mean() < 1e-4 and diff.max() < 5 * tol["po"], (net, k, what, diff.max())
+                    _diag(f"{name} {net}/{k} fp32 max abs vs {what} {diff.max():.2e} frac {(diff > tol['po']).mean():.1e} "
+                          f"(kink margin {margin:.1e})")
+                    assert (diff > tol["po"]).mean() < 1e-2 and diff.max() < cap, (net, k, what, diff.max(), margin)
                 continue
             rel = _delta_rel(v, np.asarray(init[k]), opar[k])
             _diag(f"{name} {net}/{k} delta rel vs oracle {rel:.4f}")
@@ -167,9 +177,10 @@ def test_trajectory_parity(gh, name, mode):
             errv = np.abs(st["exp_avg_sq"].cpu().numpy() - v_want) / (np.abs(v_want).max() + 1e-30)
             _diag(f"{name} {mode} moments {which}/{pname}: exp_avg {err.max():.2e} exp_avg_sq {errv.max():.2e} "
                   f"outliers {(err > t1).mean():.1e} {(errv > t2).mean():.1e}")
-            if mode == "bf16" and big:
-                assert (err > t1).mean() < 5e-3 and err.max() < 0.25, (which, pname, err.max())
-                assert (errv > t2).mean() < 5e-3 and errv.max() < 0.25, (which, pname, errv.max())
+            if big and (mode == "bf16" or margin < 1e-5):
+                few = max(4, int(5e-3 * err.size))  # (a flipped relu'(z) touches one unit's row and its bias)
+                assert (err > t1).sum() <= few and err.max() < 0.25, (which, pname, err.max())
+                assert (errv > t2).sum() <= few and errv.max() < 0.25, (which, pname, errv.max())
             else:
                 assert err.max() < t1 and errv.max() < t2, (which, pname, err.max(), errv.max())
 

@@ -35,6 +35,48 @@ print('agents', d.get('agents_per_gpu',{}).get('value'), 'ensemble', d.get('ense
       timeout -k 10 120 python tools/make_checkpoint.py $OUT/our_checkpoint.pt > $OUT/ckpt.log 2>&1; echo "ckpt rc=$?"; tail -2 $OUT/ckpt.log ;;
     groupscan)
       timeout -k 10 300 python tools/group_scan.py > $OUT/group_scan.txt 2>&1; rc=$?; echo "groupscan rc=$rc"; stop_if_killed $rc groupscan; grep -v Dataset $OUT/group_scan.txt | cut -c1-300 ;;
+    membench)
+      for k in 8 1; do timeout -k 10 120 tools/membench3 $k > $OUT/membench3_k$k.txt 2>&1; rc=$?; stop_if_killed $rc membench; done
+      cat $OUT/membench3_k8.txt; cat $OUT/membench3_k1.txt ;;
+    stampsgroup)
+      python -m iqlpref_amd.build --stamps > $OUT/build_stamps.log 2>&1 || { echo "stamps build failed"; tail -5 $OUT/build_stamps.log; exit 1; }
+      for k in 0 1 2; do
+        STAMP_GROUP=8 STAMP_GRAPH=8 STAMP_KERNEL=$k timeout -k 10 120 python tools/stamps.py bf16 > $OUT/stamps_g8_k$k.txt 2>&1; rc=$?; stop_if_killed $rc stampsgroup
+      done
+      grep -v Dataset $OUT/stamps_g8_k2.txt | cut -c1-400 | head -40 ;;
+    groupab)
+      # group of 8: the committed build (libiqlhip_prev.so, tools/build_prev.sh) against the working tree
+      for round in 1 2; do for lib in libiqlhip_prev.so libiqlhip.so; do
+        echo "== $lib" >> $OUT/groupab.txt
+        IQLHIP_LIB=$PWD/iqlpref_amd/$lib timeout -k 10 200 python tools/group_scan.py 8 2>&1 | grep -v "Dataset\|amdgpu.ids" >> $OUT/groupab.txt; rc=$?; stop_if_killed $rc groupab
+      done; done
+      cut -c1-300 $OUT/groupab.txt ;;
+    grouptests)
+      timeout -k 10 600 python -m pytest tests -m gpu -q -x -k "seed_group or seeds_per_gpu or continue or group_close or shapes_beyond or trajectory_parity" > $OUT/grouptests.log 2>&1
+      rc=$?; echo "grouptests rc=$rc"; stop_if_killed $rc grouptests; tail -5 $OUT/grouptests.log | cut -c1-300; [ $rc = 0 ] || exit 1 ;;
+    stampsall)
+      python -m iqlpref_amd.build --stamps > $OUT/build_stamps.log 2>&1 || { echo "stamps build failed"; tail -5 $OUT/build_stamps.log; exit 1; }
+      STAMP_GROUP=8 STAMP_GRAPH=8 STAMP_ALL=1 timeout -k 10 120 python tools/stamps.py bf16 > $OUT/stamps_g8_all.txt 2>&1; rc=$?; stop_if_killed $rc stampsall
+      grep -v Dataset $OUT/stamps_g8_all.txt | cut -c1-200
+      for m in 3 6; do
+        STAMP_GROUP=8 STAMP_GRAPH=8 STAMP_MEMBER=$m timeout -k 10 120 python tools/stamps.py bf16 > $OUT/stamps_g8_m$m.txt 2>&1; rc=$?; stop_if_killed $rc stampsall
+        echo "--- member $m"; grep -v Dataset $OUT/stamps_g8_m$m.txt | cut -c1-420
+      done ;;
+    abvariant)
+      # A/B of iqlpref_amd/libiqlhip_$VARIANT.so against the product build: one seed, then a group of 8
+      bash tools/ab.sh iqlpref_amd/libiqlhip.so iqlpref_amd/libiqlhip_$VARIANT.so > $OUT/ab_$VARIANT.txt 2>&1; rc=$?; stop_if_killed $rc ab
+      cat $OUT/ab_$VARIANT.txt
+      for round in 1 2; do for lib in libiqlhip.so libiqlhip_$VARIANT.so; do
+        echo "== $lib" >> $OUT/ab_${VARIANT}_group.txt
+        IQLHIP_LIB=$PWD/iqlpref_amd/$lib timeout -k 10 200 python tools/group_scan.py 8 2>&1 | grep -v Dataset >> $OUT/ab_${VARIANT}_group.txt; rc=$?; stop_if_killed $rc abgroup
+      done; done
+      cut -c1-300 $OUT/ab_${VARIANT}_group.txt ;;
+    pmcfull)
+      # ONE counter pass over bench.py's default regions (incl. the 20,000-step sustained one): the
+      # command that aborted in r2m (INVALID_PACKET_FORMAT) before the library bounded its queue depth
+      export TMPDIR=/tmp
+      timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmcfull -- python bench.py --steps 500 --warmup 100 --no-cpu-baseline --no-relabel --agents-per-gpu 0 --ensemble-q 0 --min-timed-s 0.05 > $OUT/pmcfull.json 2> $OUT/pmcfull.err
+      rc=$?; echo "pmcfull rc=$rc"; tail -c 600 $OUT/pmcfull.json; tail -5 $OUT/pmcfull.err | cut -c1-300; rm -rf $OUT/pmcfull; stop_if_killed $rc pmcfull ;;
     profile)
       bash tools/profile.sh $TAG > $OUT/profile.log 2>&1; rc=$?; echo "profile rc=$rc"; tail -5 $OUT/profile.log | cut -c1-300; [ $rc = 0 ] || exit 1 ;;
   esac

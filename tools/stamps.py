@@ -30,14 +30,20 @@ tr = bench.build_trainer(ia, torch, dev, 1, prec)
 _K = int(os.environ.get("STAMP_GROUP", "1"))
 grp = None
 dbg = torch.zeros((3, 512, 8, 2), dtype=torch.int64, device=dev)
+dbg_all = [dbg]
 if _K > 1:
-    # the group copies its members' descriptors when it is created: attach the buffer first
-    tr._ensure_handle(bench.BATCH)
-    _lib.check(lib.iqlhip_trainer_set_debug(tr._handle, C.c_void_p(dbg.data_ptr())))
-    grp = ia.SeedGroup([tr] + [bench.build_trainer(ia, torch, dev, 1 + i, prec) for i in range(1, _K)], mode="group")
+    # the group copies its members' descriptors when it is created: attach the buffers first
+    # (every member gets its own: STAMP_ALL=1 prints when each member's work-groups ran)
+    members = [tr] + [bench.build_trainer(ia, torch, dev, 1 + i, prec) for i in range(1, _K)]
+    dbg_all = [dbg] + [torch.zeros_like(dbg) for _ in range(1, _K)]
+    for t_, d_ in zip(members, dbg_all):
+        t_._ensure_handle(bench.BATCH)
+        _lib.check(lib.iqlhip_trainer_set_debug(t_._handle, C.c_void_p(d_.data_ptr())))
+    grp = ia.SeedGroup(members, mode="group")
     grp.train_steps(buf, 200, bench.BATCH, graph_unroll=0)
     torch.cuda.synchronize()
-    dbg.zero_()
+    for d_ in dbg_all:
+        d_.zero_()
 else:
     tr.train_steps(buf, 200, bench.BATCH, return_losses=False, graph_unroll=0)
     _lib.check(lib.iqlhip_trainer_set_debug(tr._handle, C.c_void_p(dbg.data_ptr())))
@@ -49,8 +55,28 @@ if grp is not None:
 else:
     tr.train_steps(buf, max(_g, 1), bench.BATCH, return_losses=False, graph_unroll=_g)
 torch.cuda.synchronize()
-d = dbg.cpu().numpy().astype(np.float64)
 names = ["k_forward", "k_backward", "k_update"]
+if _K > 1 and os.environ.get("STAMP_ALL"):
+    # when did the work-groups of each member run inside the group launches (one line per kernel
+    # and member: first start, last end, median / max work-group duration; times from the first
+    # work-group start of that kernel over all members)
+    allw = [d_.cpu().numpy().astype(np.float64)[:, :, :, 0] for d_ in dbg_all]
+    for k in range(3):
+        starts = [w[k][w[k][:, 0] > 0][:, 0].min() for w in allw if (w[k][:, 0] > 0).any()]
+        if not starts:
+            continue
+        t0 = min(starts)
+        tend = max(w[k].max() for w in allw)
+        print(f"{names[k]}: whole launch span {(tend - t0) * 10:.0f} ns over {_K} members")
+        for mi, w in enumerate(allw):
+            ww = w[k][w[k][:, 0] > 0]
+            dur = (ww.max(axis=1) - ww[:, 0]) * 10
+            busy = dur > 200  # (idle / padding work-groups write only their start stamp)
+            st = (ww[:, 0] - t0) * 10
+            print(f"   member {mi}: {len(ww):4d} blocks  start {st.min():6.0f} .. {st.max():6.0f}  "
+                  f"end max {(ww.max() - t0) * 10:6.0f}  duration med {np.median(dur[busy]):6.0f} max {dur.max():6.0f}")
+    sys.exit(0)
+d = dbg_all[int(os.environ.get("STAMP_MEMBER", "0"))].cpu().numpy().astype(np.float64)  # which member's timeline
 t_first = None
 for k in range(3):
     w = d[k, :, :, 0]
