@@ -54,22 +54,19 @@ __device__ __forceinline__ void stg16(void *p, float4 v) {
 // Write-through store (sc0 sc1): the bytes leave for memory as the store executes and the line is
 // NOT kept in this XCD's L2 -- for data whose next reader is another kernel on another XCD (or the
 // same kernel one step later), so that nothing of it is dirty when the kernel ends
-// (MI355X_MICROARCH.md: "stores of each flavour"; nt is not write-through).
-__device__ __forceinline__ void stg16_wt(void *p, float4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"((u32x4_t IQL_AS1 *)p),
-               "v"(__builtin_bit_cast(u32x4_t, v))
-               : "memory");
+// (MI355X_MICROARCH.md: "stores of each flavour"; nt is not write-through).  Issued as a raw buffer
+// store with the cache-policy bits set (aux: bit 0 = sc0, bit 4 = sc1) -- a uniform base in a
+// buffer descriptor + a 32-bit per-lane byte offset -- and NOT as inline assembly: the compiler
+// must see the instruction to keep the wait state a 16-byte store needs before its data registers
+// are overwritten (an asm store without it corrupted the group-launch variant of k_update).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void *base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
 }
-// the same with a uniform (scalar-register) base and a 32-bit per-lane byte offset: no 64-bit
-// per-lane address is ever formed (each would hold two registers from the first use to the store)
-__device__ __forceinline__ void stg16_wt(const void *sbase, uint32_t voff, float4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(__builtin_bit_cast(u32x4_t, v)),
-               "s"(sbase)
-               : "memory");
+__device__ __forceinline__ void stg16_wt(const void *base, uint32_t byte_off, float4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), buffer_of(base), byte_off, 0, 0x11);
 }
-__device__ __forceinline__ void stg16(const void *sbase, uint32_t voff, float4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(__builtin_bit_cast(u32x4_t, v)), "s"(sbase)
-               : "memory");
+__device__ __forceinline__ void stg16(const void *base, uint32_t byte_off, float4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), buffer_of(base), byte_off, 0, 0);
 }
 __device__ __forceinline__ void stg8(void *p, uint2 v) {
   *(u32x2_t IQL_AS1 *)p = __builtin_bit_cast(u32x2_t, v);

@@ -1217,19 +1217,25 @@ __device__ __forceinline__ void write_adam_coef(const TrainerDesc &D, const DevA
 #ifndef IQL_WT_STATE
 #define IQL_WT_STATE 1
 #endif
-__device__ __forceinline__ void state_store(float *p, float4 v) {
+__device__ __forceinline__ void state_store(const float *base, int64_t elem, float4 v) {  // uniform base, lane element
 #if IQL_WT_STATE
-  stg16_wt(p, v);
+  stg16_wt(base, (uint32_t)elem * 4u, v);
 #else
-  stg16(p, v);
+  stg16(base, (uint32_t)elem * 4u, v);
 #endif
 }
-__device__ __forceinline__ void state_store(const void *sbase, uint32_t voff, float4 v) {  // uniform base + lane offset
-#if IQL_WT_STATE
-  stg16_wt(sbase, voff, v);
-#else
-  stg16(sbase, voff, v);
-#endif
+
+// s += the 8 (bf16) / 4 (fp32) values of one 16-byte operand fragment, pairwise, in a fixed order
+template <bool BF16>
+__device__ __forceinline__ void frag_acc(float &s, const uint4 &f) {
+  if constexpr (BF16) {
+    const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += bf2f((uint16_t)(w[i] & 0xffff)) + bf2f((uint16_t)(w[i] >> 16));
+  } else {
+    const float4 v = __builtin_bit_cast(float4, f);
+    s += (v.x + v.y) + (v.z + v.w);
+  }
 }
 
 constexpr int UKC = 8;  // batch k-steps per register chunk in the weight-gradient GEMM
@@ -1546,71 +1552,11 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   // ---- 2. dW^T tile on MFMA: A = layer input X^T, B = dZ^T (fragment-major) ----
   const T *Xsrc = reinterpret_cast<const T *>(it.Xsrc);
   const T *Zsrc = reinterpret_cast<const T *>(it.Zsrc);
-  // wave (wo, wi) = (wave >> 1, wave & 1): in-feature tile wi x out-feature tiles UNB wo .. + UNB
-  const int wo = wave >> 1, wi = wave & 1;
-  const int ib = i0 + 16 * wi, ob = o0 + 16 * UNB * wo;
-  f32x4 acc[UNB];
-  float bsum[UNB];
-#pragma unroll
-  for (int b = 0; b < UNB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f}, bsum[b] = 0.f;
   const bool do_bias = i0 == 0;
-  const bool wave_bias = do_bias && wi == 0;
-  // Branch-free operand stream: in-features always exist here (Idim = H), out-feature tiles
-  // beyond Opad (layer 3: one tile) re-read the last tile -- their products land in tile rows
-  // that are never stored -- and k-steps beyond nk re-read the last one and are skipped by the
-  // (scalar) guard around the MFMA only.
   const int ntile_o = Opad >> 4;
-  int ot[UNB];
-#pragma unroll
-  for (int b = 0; b < UNB; ++b) ot[b] = (ob >> 4) + b < ntile_o ? (ob >> 4) + b : ntile_o - 1;
-  // Operand fragments are requested FIRST, the optimiser state behind them: the MFMAs (and the
-  // LDS hand-over to the row-ordered Adam pass) then start as soon as the fragments are in, while
-  // the state is still streaming (+0.8 % measured).  First chunk straight-line: a loop
-  // pre-header would drain every pending load.
   // (addresses as uniform base + ONE 32-bit lane offset: global_load ... v_off, s[base:base+1];
   // a 64-bit per-lane address per fragment costs two registers each while the loads are issued)
   const uint32_t lane16 = (uint32_t)lane * 16u;
-  auto load_frags = [&](const int k0, uint4(&xf)[UKC], uint4(&zf)[UKC][UNB]) {
-    const char *const xb = reinterpret_cast<const char *>(Xsrc) + (size_t)((ib >> 4) * nk) * 1024;
-    const char *zb[UNB];
-#pragma unroll
-    for (int b = 0; b < UNB; ++b) zb[b] = reinterpret_cast<const char *>(Zsrc) + (size_t)(ot[b] * nk) * 1024;
-#pragma unroll
-    for (int ks = 0; ks < UKC; ++ks) {
-      const int kk = k0 + ks < nk ? k0 + ks : nk - 1;  // (one fragment = 64 lanes x 16 B = 1 KiB, both precisions)
-      xf[ks] = ldg16(xb + (size_t)kk * 1024 + lane16);
-#pragma unroll
-      for (int b = 0; b < UNB; ++b) zf[ks][b] = ldg16(zb[b] + (size_t)kk * 1024 + lane16);
-    }
-  };
-  auto mma_frags = [&](const int k0, const uint4(&xf)[UKC], const uint4(&zf)[UKC][UNB]) {
-#pragma unroll
-    for (int ks = 0; ks < UKC; ++ks) {
-      if (k0 + ks < nk) {
-#pragma unroll
-        for (int b = 0; b < UNB; ++b) {
-          if (wave_bias) {  // bias gradient = row sums of dZ^T (this lane: its out-feature, 1/4 of K)
-            if constexpr (BF16) {
-              const uint32_t w[4] = {zf[ks][b].x, zf[ks][b].y, zf[ks][b].z, zf[ks][b].w};
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-                bsum[b] += bf2f((uint16_t)(w[i] & 0xffff)) + bf2f((uint16_t)(w[i] >> 16));
-            } else {
-              const float4 f = __builtin_bit_cast(float4, zf[ks][b]);
-              bsum[b] += (f.x + f.y) + (f.z + f.w);
-            }
-          }
-          P::mma(xf[ks], zf[ks][b], acc[b]);
-        }
-      }
-    }
-  };
-  // (Tried: the operand panels of a tile through LDS-DMA -- 48 distinct fragments instead of the
-  // 128 the eight waves load between them.  No gain: 3.24 vs 3.14 us per tile work-group, the
-  // wait for ALL fragments plus a barrier costs what the L1 port saves.)
-  uint4 xf0[UKC], zf0[UKC][UNB];
-  load_frags(0, xf0, zf0);
-  __builtin_amdgcn_sched_barrier(0);
 
   // ---- 1. optimiser state, row order: thread -> (row tr + 16 pass, columns 4 tc .. +3) ----
   const int tr = tid / UTPR, tc4 = (tid % UTPR) * 4;
@@ -1643,37 +1589,178 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     pb = ldg(g_params + eb), mb = ldg(g_m + eb), vb = ldg(g_v + eb);
     tb = ldg((has_target ? g_target + it.toff_b : g_params + it.off_b) + ob_);
   };
-  // LAT (one seed per launch: a latency chain on an idle chip): the state is requested right
-  // behind the operand fragments, everything in flight at once.  !LAT (several seeds per launch:
-  // throughput): the state is requested only once the fragments have been consumed -- 96 fewer
-  // live VGPRs, twice the work-groups per CU, and other work-groups hide the second round trip.
-  if constexpr (LAT) load_state();
-  STAMP(2, 1);
 
-  __builtin_amdgcn_sched_barrier(0);
-  mma_frags(0, xf0, zf0);
-#pragma unroll 1
-  for (int k0 = UKC; k0 < nk; k0 += UKC) {
-    uint4 xf[UKC], zf[UKC][UNB];
-    load_frags(k0, xf, zf);
-    mma_frags(k0, xf, zf);
-  }
-  if constexpr (!LAT) {
+  if constexpr (LAT) {
+    // ======== one seed per launch: a latency chain on an idle chip, 8 waves ========
+    // wave (wo, wi) = (wave >> 1, wave & 1): in-feature tile wi x out-feature tiles UNB wo .. + UNB
+    const int wo = wave >> 1, wi = wave & 1;
+    const int ib = i0 + 16 * wi, ob = o0 + 16 * UNB * wo;
+    f32x4 acc[UNB];
+    float bsum[UNB];
+#pragma unroll
+    for (int b = 0; b < UNB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f}, bsum[b] = 0.f;
+    const bool wave_bias = do_bias && wi == 0;
+    // Branch-free operand stream: in-features always exist here (Idim = H), out-feature tiles
+    // beyond Opad (layer 3: one tile) re-read the last tile -- their products land in tile rows
+    // that are never stored -- and k-steps beyond nk re-read the last one and are skipped by the
+    // (scalar) guard around the MFMA only.
+    int ot[UNB];
+#pragma unroll
+    for (int b = 0; b < UNB; ++b) ot[b] = (ob >> 4) + b < ntile_o ? (ob >> 4) + b : ntile_o - 1;
+    // Operand fragments are requested FIRST, the optimiser state behind them: the MFMAs (and the
+    // LDS hand-over to the row-ordered Adam pass) then start as soon as the fragments are in, while
+    // the state is still streaming (+0.8 % measured).  First chunk straight-line: a loop
+    // pre-header would drain every pending load.
+    auto load_frags = [&](const int k0, uint4(&xf)[UKC], uint4(&zf)[UKC][UNB]) {
+      const char *const xb = reinterpret_cast<const char *>(Xsrc) + (size_t)((ib >> 4) * nk) * 1024;
+      const char *zb[UNB];
+#pragma unroll
+      for (int b = 0; b < UNB; ++b) zb[b] = reinterpret_cast<const char *>(Zsrc) + (size_t)(ot[b] * nk) * 1024;
+#pragma unroll
+      for (int ks = 0; ks < UKC; ++ks) {
+        const int kk = k0 + ks < nk ? k0 + ks : nk - 1;  // (one fragment = 64 lanes x 16 B = 1 KiB, both precisions)
+        xf[ks] = ldg16(xb + (size_t)kk * 1024 + lane16);
+#pragma unroll
+        for (int b = 0; b < UNB; ++b) zf[ks][b] = ldg16(zb[b] + (size_t)kk * 1024 + lane16);
+      }
+    };
+    auto mma_frags = [&](const int k0, const uint4(&xf)[UKC], const uint4(&zf)[UKC][UNB]) {
+#pragma unroll
+      for (int ks = 0; ks < UKC; ++ks) {
+        if (k0 + ks < nk) {
+#pragma unroll
+          for (int b = 0; b < UNB; ++b) {
+            if (wave_bias) frag_acc<BF16>(bsum[b], zf[ks][b]);  // bias gradient = row sums of dZ^T
+            P::mma(xf[ks], zf[ks][b], acc[b]);
+          }
+        }
+      }
+    };
+    // (Tried: the operand panels of a tile through LDS-DMA -- 48 distinct fragments instead of the
+    // 128 the eight waves load between them.  No gain: 3.24 vs 3.14 us per tile work-group, the
+    // wait for ALL fragments plus a barrier costs what the L1 port saves.)
+    uint4 xf0[UKC], zf0[UKC][UNB];
+    load_frags(0, xf0, zf0);
     __builtin_amdgcn_sched_barrier(0);
-    load_state();
-  }
-  // C/D layout: lane (r, q) of acc[b] holds dW[ob + 16 b + r][ib + 4 q + k]
+    load_state();  // right behind the operand fragments: everything in flight at once
+    STAMP(2, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frags(0, xf0, zf0);
+#pragma unroll 1
+    for (int k0 = UKC; k0 < nk; k0 += UKC) {
+      uint4 xf[UKC], zf[UKC][UNB];
+      load_frags(k0, xf, zf);
+      mma_frags(k0, xf, zf);
+    }
+    // C/D layout: lane (r, q) of acc[b] holds dW[ob + 16 b + r][ib + 4 q + k]
 #pragma unroll
-  for (int b = 0; b < UNB; ++b)
-    *reinterpret_cast<f32x4 *>(&tile[(16 * UNB * wo + 16 * b + r) * ULD + 16 * wi + 4 * q]) = acc[b];
-  if (wave_bias) {
+    for (int b = 0; b < UNB; ++b)
+      *reinterpret_cast<f32x4 *>(&tile[(16 * UNB * wo + 16 * b + r) * ULD + 16 * wi + 4 * q]) = acc[b];
+    if (wave_bias) {
 #pragma unroll
-    for (int b = 0; b < UNB; ++b) {
-      float bs = bsum[b];
-      bs = xor32_sum(xor16_sum(bs));
-      if (q == 0) bgrad[16 * UNB * wo + 16 * b + r] = bs;
+      for (int b = 0; b < UNB; ++b) {
+        float bs = bsum[b];
+        bs = xor32_sum(xor16_sum(bs));
+        if (q == 0) bgrad[16 * UNB * wo + 16 * b + r] = bs;
+      }
+    }
+  } else {
+    // ======== several seeds per launch: throughput, 4 waves, four work-groups per CU ========
+    // In-kernel stamps of round 3 (tools/stamps.py STAMP_ALL, 8 seeds per launch): with the chip
+    // full a tile work-group spends 2-8 us just getting its loads ISSUED -- the CU's vector-memory
+    // pipeline, not latency, bounds the launch (requesting the state earlier, through LDS-DMA, made
+    // the launch 20 % slower).  Of the 172 KB a 64 x 32 tile moves through that pipeline, 96 KB were
+    // operand fragments for 48 KB of distinct ones: every wave loaded its own copy of the X / Z
+    // fragments it shared with a neighbour.  Here TWO waves do the GEMM -- wave g: out-feature tiles
+    // 2g, 2g+1 x BOTH in-feature tiles, 32 KB each, 64 KB per tile -- with the k-steps pipelined
+    // GIF deep so that the registers stay below the 4-waves-per-SIMD budget; the other two waves,
+    // which have no operands to hold, request their half of the optimiser state right away.
+    // Every accumulator still sums its k-steps in ascending order: results are bit-identical.
+    #ifndef IQL_GIF
+#define IQL_GIF 4  // k-steps in flight per GEMM wave (5 spills two registers at the 128-register budget)
+#endif
+    constexpr int GNB = 2, GNI = UTI / 16, GIF = IQL_GIF;
+    static_assert(UT == 256 && UTO == 64, "two GEMM waves cover a 64-row tile");
+    const bool gemm_wave = wave < 2;  // (scalar)
+    const bool wave_bias = do_bias && gemm_wave;
+    f32x4 acc[GNB][GNI];
+    float bsum[GNB];
+#pragma unroll
+    for (int b = 0; b < GNB; ++b) {
+      bsum[b] = 0.f;
+#pragma unroll
+      for (int c = 0; c < GNI; ++c) acc[b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#ifndef IQL_G2_EARLY
+#define IQL_G2_EARLY 1
+#endif
+    if (!gemm_wave) {
+#if IQL_G2_EARLY
+      load_state();
+#endif
+      STAMP(2, 1);
+    } else {
+      const char *xb[GNI], *zb[GNB];
+#pragma unroll
+      for (int c = 0; c < GNI; ++c) xb[c] = reinterpret_cast<const char *>(Xsrc) + (size_t)(((i0 >> 4) + c) * nk) * 1024;
+#pragma unroll
+      for (int b = 0; b < GNB; ++b) {
+        const int t_ = (o0 >> 4) + GNB * wave + b;
+        zb[b] = reinterpret_cast<const char *>(Zsrc) + (size_t)((t_ < ntile_o ? t_ : ntile_o - 1) * nk) * 1024;
+      }
+      uint4 xf[UKC][GNI], zf[UKC][GNB];  // (a k-step's registers are live from its issue to its MFMAs only)
+      auto issue = [&](const int k0, const int ks) {
+        const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
+#pragma unroll
+        for (int c = 0; c < GNI; ++c) xf[ks][c] = ldg16(xb[c] + (size_t)kk * 1024 + lane16);
+#pragma unroll
+        for (int b = 0; b < GNB; ++b) zf[ks][b] = ldg16(zb[b] + (size_t)kk * 1024 + lane16);
+      };
+      auto chunk = [&](const int k0) {
+#pragma unroll
+        for (int ks = 0; ks < GIF; ++ks) issue(k0, ks);
+        if (k0 == 0) STAMP(2, 1);
+#pragma unroll
+        for (int ks = 0; ks < UKC; ++ks) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (k0 + ks < nk) {
+#pragma unroll
+            for (int b = 0; b < GNB; ++b) {
+              if (wave_bias) frag_acc<BF16>(bsum[b], zf[ks][b]);
+#pragma unroll
+              for (int c = 0; c < GNI; ++c) P::mma(xf[ks][c], zf[ks][b], acc[b][c]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (ks + GIF < UKC) issue(k0, ks + GIF);  // into the registers the k-step just consumed freed
+        }
+      };
+      chunk(0);  // straight-line first chunk (a loop pre-header would drain the pending loads)
+#pragma unroll 1
+      for (int k0 = UKC; k0 < nk; k0 += UKC) chunk(k0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_state();  // the operand registers are free now
+      // C/D layout: lane (r, q) of acc[b][c] holds dW[o0 + 32 g + 16 b + r][i0 + 16 c + 4 q + k]
+#pragma unroll
+      for (int b = 0; b < GNB; ++b)
+#pragma unroll
+        for (int c = 0; c < GNI; ++c)
+          *reinterpret_cast<f32x4 *>(&tile[(16 * GNB * wave + 16 * b + r) * ULD + 16 * c + 4 * q]) = acc[b][c];
+      if (wave_bias) {
+#pragma unroll
+        for (int b = 0; b < GNB; ++b) {
+          float bs = bsum[b];
+          bs = xor32_sum(xor16_sum(bs));
+          if (q == 0) bgrad[16 * GNB * wave + 16 * b + r] = bs;
+        }
+      }
     }
   }
+#if !IQL_G2_EARLY
+  if constexpr (!LAT) {
+    if (wave >= 2) load_state();
+  }
+#endif
   __syncthreads();
   STAMP(2, 3);
 
@@ -1701,11 +1788,11 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     if (o < Odim && i < Idim) {
       const int64_t e = it.off_w + (int64_t)o * Idim + i;
       const int64_t te = it.toff_w + (int64_t)o * Idim + i;
-      state_store(g_params + e, make_float4(p[0], p[1], p[2], p[3]));
-      state_store(g_m + e, make_float4(m[0], m[1], m[2], m[3]));
-      state_store(g_v + e, make_float4(v[0], v[1], v[2], v[3]));
+      state_store(g_params, e, make_float4(p[0], p[1], p[2], p[3]));  // (arenas are far below 4 GB)
+      state_store(g_m, e, make_float4(m[0], m[1], m[2], m[3]));
+      state_store(g_v, e, make_float4(v[0], v[1], v[2], v[3]));
       if (g_grads) stg16(g_grads + e, make_float4(g[0], g[1], g[2], g[3]));
-      if (has_target) state_store(g_target + te, make_float4(tv[0], tv[1], tv[2], tv[3]));
+      if (has_target) state_store(g_target, te, make_float4(tv[0], tv[1], tv[2], tv[3]));
       // 4 consecutive k of one row are contiguous in the fragment-major copies
       store4T<BF16>(wc + fidx<P>(o, i, nkw), p);
       if (has_target) store4T<BF16>(tc + fidx<P>(o, i, nkw), tv);

@@ -46,11 +46,17 @@ print('agents', d.get('agents_per_gpu',{}).get('value'), 'ensemble', d.get('ense
       grep -v Dataset $OUT/stamps_g8_k2.txt | cut -c1-400 | head -40 ;;
     groupab)
       # group of 8: the committed build (libiqlhip_prev.so, tools/build_prev.sh) against the working tree
-      for round in 1 2; do for lib in libiqlhip_prev.so libiqlhip.so; do
+      for round in 1 2; do for lib in libiqlhip_prev.so libiqlhip.so $EXTRA_LIBS; do
         echo "== $lib" >> $OUT/groupab.txt
         IQLHIP_LIB=$PWD/iqlpref_amd/$lib timeout -k 10 200 python tools/group_scan.py 8 2>&1 | grep -v "Dataset\|amdgpu.ids" >> $OUT/groupab.txt; rc=$?; stop_if_killed $rc groupab
       done; done
       cut -c1-300 $OUT/groupab.txt ;;
+    groupbisect)
+      # which build variants keep a seed group bit-identical to the seeds alone
+      for lib in $EXTRA_LIBS; do
+        IQLHIP_LIB=$PWD/iqlpref_amd/$lib timeout -k 10 300 python -m pytest tests -m gpu -q -k "seed_group_matches_separate_runs and group" > $OUT/bisect_$lib.log 2>&1
+        echo "$lib rc=$?"; tail -2 $OUT/bisect_$lib.log | cut -c1-200
+      done ;;
     grouptests)
       timeout -k 10 600 python -m pytest tests -m gpu -q -x -k "seed_group or seeds_per_gpu or continue or group_close or shapes_beyond or trajectory_parity" > $OUT/grouptests.log 2>&1
       rc=$?; echo "grouptests rc=$rc"; stop_if_killed $rc grouptests; tail -5 $OUT/grouptests.log | cut -c1-300; [ $rc = 0 ] || exit 1 ;;
