@@ -102,6 +102,7 @@ struct DevArgs {
 // Device-written counters / metrics.
 struct AdamCoef {
   float one_m_b1, b2, one_m_b2, neg_step[3], bc2_sqrt, eps;  // neg_step per group q / v / actor
+  float inv_bc2_sqrt, pad_;                                    // 1 / sqrt(1 - beta2^t) (IQL_ADAM_FAST)
 };
 
 struct DevCtr {

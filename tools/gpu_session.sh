@@ -68,6 +68,9 @@ print('agents', d.get('agents_per_gpu',{}).get('value'), 'ensemble', d.get('ense
         STAMP_GROUP=8 STAMP_GRAPH=8 STAMP_MEMBER=$m timeout -k 10 120 python tools/stamps.py bf16 > $OUT/stamps_g8_m$m.txt 2>&1; rc=$?; stop_if_killed $rc stampsall
         echo "--- member $m"; grep -v Dataset $OUT/stamps_g8_m$m.txt | cut -c1-420
       done ;;
+    varianttests)
+      IQLHIP_LIB=$PWD/iqlpref_amd/libiqlhip_$VARIANT.so IQL_TEST_DIAG=$OUT/diag_$VARIANT.txt timeout -k 10 900 python -m pytest tests -m gpu -q > $OUT/tests_$VARIANT.log 2>&1
+      rc=$?; echo "varianttests rc=$rc"; stop_if_killed $rc varianttests; tail -8 $OUT/tests_$VARIANT.log | cut -c1-300 ;;
     abvariant)
       # A/B of iqlpref_amd/libiqlhip_$VARIANT.so against the product build: one seed, then a group of 8
       bash tools/ab.sh iqlpref_amd/libiqlhip.so iqlpref_amd/libiqlhip_$VARIANT.so > $OUT/ab_$VARIANT.txt 2>&1; rc=$?; stop_if_killed $rc ab
