@@ -238,8 +238,8 @@ def main():
     while True:
         barrier()
         torch.cuda.synchronize()
+        ev0.record()  # same stream the library launches on (torch's current stream); idle: stamps at once
         t0 = time.perf_counter()
-        ev0.record()  # same stream the library launches on (torch's current stream)
         run(K)
         ev1.record()
         torch.cuda.synchronize()
@@ -299,7 +299,7 @@ def main():
         upd_us = ev_us[2] * scale
         achieved = upd_bytes / (upd_us * 1e-6) / 1e9  # GB/s of k_update
         traffic, traffic_src = None, None
-        tname = os.environ.get("IQL_TRAFFIC_PROFILE", "r02_traffic.json")
+        tname = os.environ.get("IQL_TRAFFIC_PROFILE", "r03_traffic.json")
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):  # PMC passes (separate rocprofv3 --pmc runs, tools/profile.sh)
             with open(tpath) as f:

@@ -178,7 +178,11 @@ def require_gpu(device):
 
 
 def stream_ptr():
+    """The current HIP stream of the current device as a void* (what every entry point launches on)."""
     import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:  # (no Stream object: ~0.3 us instead of ~3 us on the launch path)
+        return C.c_void_p(raw(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

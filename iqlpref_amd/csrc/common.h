@@ -68,6 +68,12 @@ __device__ __forceinline__ void stg16_wt(const void *base, uint32_t byte_off, fl
 __device__ __forceinline__ void stg16(const void *base, uint32_t byte_off, float4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), buffer_of(base), byte_off, 0, 0);
 }
+__device__ __forceinline__ void stg8_wt(const void *base, uint32_t byte_off, uint2 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), buffer_of(base), byte_off, 0, 0x11);
+}
+__device__ __forceinline__ void stg4_wt(const void *base, uint32_t byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), buffer_of(base), byte_off, 0, 0x11);
+}
 __device__ __forceinline__ void stg8(void *p, uint2 v) {
   *(u32x2_t IQL_AS1 *)p = __builtin_bit_cast(u32x2_t, v);
 }

@@ -1253,6 +1253,35 @@ __device__ __forceinline__ void frag_acc(float &s, const uint4 &f) {
   }
 }
 
+// IQL_WT_ALL (A/B build): also the compute-precision copies and the layer-1 strips' state leave
+// write-through, so that k_update ends with (almost) nothing dirty in the L2s.
+#ifndef IQL_WT_ALL
+#define IQL_WT_ALL 0
+#endif
+template <bool BF16>
+__device__ __forceinline__ void copy_store4(typename Prec<BF16>::T *base, size_t elem, const float v[4]) {
+#if IQL_WT_ALL
+  using P = Prec<BF16>;
+  if constexpr (BF16) {
+    uint2 u;
+    u.x = (uint32_t)P::from_f32(v[0]) | ((uint32_t)P::from_f32(v[1]) << 16);
+    u.y = (uint32_t)P::from_f32(v[2]) | ((uint32_t)P::from_f32(v[3]) << 16);
+    stg8_wt(base, (uint32_t)elem * 2u, u);
+  } else {
+    stg16_wt(base, (uint32_t)elem * 4u, make_float4(v[0], v[1], v[2], v[3]));
+  }
+#else
+  store4T<BF16>(base + elem, v);
+#endif
+}
+__device__ __forceinline__ void state_store1(float *base, int64_t elem, float v) {
+#if IQL_WT_ALL
+  stg4_wt(base, (uint32_t)elem * 4u, v);
+#else
+  stg(base + elem, v);
+#endif
+}
+
 constexpr int UKC = 8;  // batch k-steps per register chunk in the weight-gradient GEMM
 
 // One work-group owns the gradient tile dW[o0..o0+64)[i0..i0+32) (192 work-groups
@@ -1528,12 +1557,12 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
         float p_ = pf[k], m_ = mf[k], v_ = vf[k];
         adam_apply(p_, m_, v_, g, coef, neg_step);
         tile[ol * TLD + i] = p_;
-        stg(g_params + fbase + e, p_), stg(g_m + fbase + e, m_), stg(g_v + fbase + e, v_);
+        state_store1(g_params, fbase + e, p_), state_store1(g_m, fbase + e, m_), state_store1(g_v, fbase + e, v_);
         if (g_grads) stg(g_grads + fbase + e, g);
         if (has_target) {
           const float t_ = polyak(D, tf[k], p_);
           tile2[ol * TLD + i] = t_;
-          stg(g_target + tbase + e, t_);
+          state_store1(g_target, tbase + e, t_);
         }
       }
     }
@@ -1553,12 +1582,12 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       const int ol = e / cpr, i = (e - ol * cpr) * 4;
       const float4 p4 = *reinterpret_cast<const float4 *>(&tile[ol * TLD + i]);
       float pv4[4] = {p4.x, p4.y, p4.z, p4.w};
-      store4T<BF16>(wc + fidx<P>(o0 + ol, i, nkw), pv4);
+      copy_store4<BF16>(wc, fidx<P>(o0 + ol, i, nkw), pv4);
       if (has_target) {
         const float4 t4 = *reinterpret_cast<const float4 *>(&tile2[ol * TLD + i]);
         float tv4[4] = {i < Idim ? t4.x : 0.f, i + 1 < Idim ? t4.y : 0.f, i + 2 < Idim ? t4.z : 0.f,
                         i + 3 < Idim ? t4.w : 0.f};
-        store4T<BF16>(tc + fidx<P>(o0 + ol, i, nkw), tv4);
+        copy_store4<BF16>(tc, fidx<P>(o0 + ol, i, nkw), tv4);
       }
     }
     STAMP(2, 4);
@@ -1692,12 +1721,15 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     // GIF deep so that the registers stay below the 4-waves-per-SIMD budget; the other two waves,
     // which have no operands to hold, request their half of the optimiser state right away.
     // Every accumulator still sums its k-steps in ascending order: results are bit-identical.
-    #ifndef IQL_GIF
-#define IQL_GIF 4  // k-steps in flight per GEMM wave (5 spills two registers at the 128-register budget)
+    #ifndef IQL_GW
+#define IQL_GW 2  // GEMM waves per tile (A/B: 1 = one wave loads every distinct fragment exactly once)
 #endif
-    constexpr int GNB = 2, GNI = UTI / 16, GIF = IQL_GIF;
-    static_assert(UT == 256 && UTO == 64, "two GEMM waves cover a 64-row tile");
-    const bool gemm_wave = wave < 2;  // (scalar)
+#ifndef IQL_GIF
+#define IQL_GIF (IQL_GW == 2 ? 4 : 3)  // k-steps in flight per GEMM wave (one more spills at the 128-register budget)
+#endif
+    constexpr int GW = IQL_GW, GNB = (UTO / 16) / GW, GNI = UTI / 16, GIF = IQL_GIF;
+    static_assert(UT == 256 && UTO == 64 && (GW == 1 || GW == 2), "the GEMM waves cover a 64-row tile");
+    const bool gemm_wave = wave < GW;  // (scalar)
     const bool wave_bias = do_bias && gemm_wave;
     f32x4 acc[GNB][GNI];
     float bsum[GNB];
@@ -1810,8 +1842,8 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       if (g_grads) stg16(g_grads + e, make_float4(g[0], g[1], g[2], g[3]));
       if (has_target) state_store(g_target, te, make_float4(tv[0], tv[1], tv[2], tv[3]));
       // 4 consecutive k of one row are contiguous in the fragment-major copies
-      store4T<BF16>(wc + fidx<P>(o, i, nkw), p);
-      if (has_target) store4T<BF16>(tc + fidx<P>(o, i, nkw), tv);
+      copy_store4<BF16>(wc, fidx<P>(o, i, nkw), p);
+      if (has_target) copy_store4<BF16>(tc, fidx<P>(o, i, nkw), tv);
       if (L == 2) {  // layer 3: the [H][Opad] transposed copy k_backward reads (one unit's weights to all outputs)
         T *w3t = reinterpret_cast<T *>(it.w3t);
 #pragma unroll
@@ -1841,7 +1873,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       float pv4[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) pv4[k] = tile[(o4 + k) * ULD + il];
-      store4T<BF16>(reinterpret_cast<T *>(it.w2ct) + fidx<P>(i0 + il, o0 + o4, H / P::KM), pv4);
+      copy_store4<BF16>(reinterpret_cast<T *>(it.w2ct), fidx<P>(i0 + il, o0 + o4, H / P::KM), pv4);
     }
   }
   STAMP(2, 4);

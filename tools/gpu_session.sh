@@ -15,6 +15,7 @@ for what in "$@"; do
       IQL_TEST_DIAG=$OUT/diag.txt timeout -k 10 900 python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1
       rc=$?; echo "tests rc=$rc"; stop_if_killed $rc tests; tail -12 $OUT/tests.log | cut -c1-300 ;;
     stamps)
+      python -m iqlpref_amd.build --stamps > $OUT/build_stamps.log 2>&1 || { echo "stamps build failed"; tail -5 $OUT/build_stamps.log; exit 1; }
       for k in 0 1 2; do
         STAMP_GRAPH=8 STAMP_KERNEL=$k timeout -k 10 120 python tools/stamps.py bf16 > $OUT/stamps_k$k.txt 2>&1; rc=$?; stop_if_killed $rc stamps
       done
@@ -31,6 +32,12 @@ print('agents', d.get('agents_per_gpu',{}).get('value'), 'ensemble', d.get('ense
     bench20)
       timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/bench20.err
       rc=$?; echo "bench20 rc=$rc"; stop_if_killed $rc bench20; tail -c 1500 $OUT/bench20.json ;;
+    waitmode)
+      # host wait policy at the end of a timed block: HIP's active-wait window (us) before it blocks on the interrupt
+      for round in 1 2; do for w in 0 100 10000; do
+        ROC_ACTIVE_WAIT_TIMEOUT=$w timeout -k 10 200 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-relabel --agents-per-gpu 0 --ensemble-q 0 2>/dev/null |
+          python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('wait', $w, round(d['value']), d['ms_per_step'], d['timing']['ms_per_step_device'])" || exit 1
+      done; done ;;
     ckpt)
       timeout -k 10 120 python tools/make_checkpoint.py $OUT/our_checkpoint.pt > $OUT/ckpt.log 2>&1; echo "ckpt rc=$?"; tail -2 $OUT/ckpt.log ;;
     groupscan)

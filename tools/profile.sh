@@ -12,8 +12,11 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 3000 --warmup 300 $ARGS > $OUT/trace.json
 echo "trace done"
-# counter passes: short regions only (a counter pass serialises every dispatch and the profiler's
-# intercepted queue holds 16k packets: the 20,000-step `sustained` region overran it in r2m)
+# counter passes: short regions only.  Under a serialising counter pass, a long region of back-to-back
+# hipGraph launches ends in HSA_STATUS_ERROR_INVALID_PACKET_FORMAT: the packet the queue dumps is one of
+# OUR kernel dispatches whose `setup` field (number of grid dimensions) reads 0 -- it was rewritten on its
+# way through the profiler's intercept queue (r2m; again in round 3, r4b, with the library's queue depth
+# bounded to 6144 dispatches: depth is not the cause).  Kernel-trace passes are not affected.
 PMC="--steps 500 --warmup 100 --no-sustained $ARGS"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python bench.py $PMC > $OUT/fetch.json
 echo "fetch done"
@@ -28,6 +31,14 @@ echo "relabel done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/group -- python tools/group_scan.py 8 > $OUT/group.json
 echo "group done"
 find $OUT/group -name "*kernel_stats.csv" -exec cp {} $OUT/group8_kernel_stats.csv \;
+# ... and their fabric traffic (short region: see above)
+GROUP_SCAN_STEPS=500 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/gfetch -- python tools/group_scan.py 8 > $OUT/gfetch.json
+GROUP_SCAN_STEPS=500 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/gwrite -- python tools/group_scan.py 8 > $OUT/gwrite.json
+echo "group pmc done"
+python tools/pmc_summary.py $OUT/gfetch 1 $OUT/group8_pmc_fetch_size.json > /dev/null
+python tools/pmc_summary.py $OUT/gwrite 1 $OUT/group8_pmc_write_size.json > /dev/null
+python tools/traffic_json.py $OUT/group8_pmc_fetch_size.json $OUT/group8_pmc_write_size.json $OUT/group8_traffic.json
+rm -rf $OUT/gfetch $OUT/gwrite
 find $OUT/relabel -name "*kernel_stats.csv" -exec cp {} $OUT/relabel_kernel_stats.csv \;
 python tools/pmc_summary.py $OUT/fetch 1 $OUT/pmc_fetch_size.json > /dev/null
 python tools/pmc_summary.py $OUT/write 1 $OUT/pmc_write_size.json > /dev/null
