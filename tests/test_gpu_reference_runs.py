@@ -209,3 +209,69 @@ def test_mlp_forward_with_active_dropout_matches_the_philox_oracle():
     actor.train()
     act = actor.act(x[0].cpu().numpy(), DEV)  # ref:476-482: samples through the active-dropout net
     assert act.shape == (A,) and np.all(np.abs(act) <= 1.0)
+
+
+def test_pt_relabel_clamps_windows_handed_in_by_a_c_caller():
+    """the window arrays live on the device, the C entry point cannot check them.
+    The kernel clamps every window into the arrays (include/iqlhip.h): a window that violates the
+    precondition gives the value of the clamped window -- never an out-of-bounds read."""
+    import ctypes as C
+    from iqlpref_amd import _lib
+    from iqlpref_amd._lib import check, ptr, stream_ptr
+    from oracle import relabel_oracle as ro
+    from tests.test_gpu_relabel import make_pt
+    S, A, QL, max_ep, n_rows = 5, 3, 6, 20, 40
+    rng = np.random.default_rng(1)
+    m = make_pt(ro.make_pt_params(rng, S, A, max_ep, embd=64, pref=8, inter=256, layers=1), S, A, max_ep, 4, 256)
+    obs = torch.from_numpy(rng.standard_normal((n_rows, S)).astype(np.float32)).to(DEV)
+    act = torch.from_numpy(rng.uniform(-1, 1, (n_rows, A)).astype(np.float32)).to(DEV)
+    dev = lambda a, dt: torch.from_numpy(np.asarray(a, dtype=dt)).to(DEV)
+    #            start          len       t0     (bad)            ->   the window the kernel uses
+    bad = [(n_rows - 2, 5, 0), (-3, 4, 2), (7, 0, 1), (3, 9, 0), (10, 3, max_ep), (5, 4, -7)]
+    good = [(n_rows - 5, 5, 0), (0, 4, 2), (7, 1, 1), (3, 6, 0), (10, 3, max_ep + 1 - 3), (5, 4, 0)]
+    w, keep, _ = m._weights()
+    lib = _lib.load()
+
+    def run(wins):
+        out = torch.empty(len(wins), dtype=torch.float32, device=DEV)
+        st, ln, t0 = (dev([x[i] for x in wins], dt) for i, dt in ((0, np.int64), (1, np.int32), (2, np.int32)))
+        check(lib.iqlhip_pt_relabel(C.byref(w), ptr(obs), ptr(act), n_rows, ptr(st), ptr(ln), ptr(t0), len(wins), QL,
+                                    ptr(out), stream_ptr()))
+        return out.cpu().numpy()
+    got, want = run(bad), run(good)
+    assert np.isfinite(got).all()
+    np.testing.assert_array_equal(got, want)
+    del keep
+
+
+def test_queue_depth_bound_does_not_change_results(tmp_path):
+    """IQLHIP_MAX_INFLIGHT (read once per process): a tiny bound makes the library wait on its own
+    events every few dispatches; the run is the same bits as with the default bound."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "depth.py"
+    script.write_text('''
+import sys, hashlib
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from tests import helpers, gpu_helpers as gh
+d, hyper, data, nets = helpers.load_traj("traj_antmaze", "bf16")
+tr = gh.make_trainer(hyper, nets, "bf16", seed=5)
+buf = gh.make_buffer(hyper, data)
+for n, u in ((40, 8), (13, 0), (40, 8)):
+    tr.train_steps(buf, n, hyper["batch"], return_losses=False, graph_unroll=u)
+torch.cuda.synchronize()
+print("DIGEST", hashlib.sha256(tr._params.cpu().numpy().tobytes() + tr._target.cpu().numpy().tobytes()).hexdigest())
+''')
+    digests = []
+    for depth in ("9", "0", None):
+        env = dict(os.environ)
+        env.pop("IQLHIP_MAX_INFLIGHT", None)
+        if depth is not None:
+            env["IQLHIP_MAX_INFLIGHT"] = depth
+        p = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-1500:]
+        digests.append([l for l in p.stdout.splitlines() if l.startswith("DIGEST")][0])
+    assert digests[0] == digests[1] == digests[2]

@@ -128,7 +128,7 @@ def test_seeds_per_gpu_equals_solo_runs_bit_for_bit(tmp_path):
 
         def evaluate(actor, t):  # a value that depends on the actor handed in
             w = actor.net.linears()[2].weight
-            evals.append((t, float(w.double().sum())))
+            evals.append((t, float(w.detach().double().sum())))
             return np.array([float(w[0, 0]), 1.0]), [t]
         out = ia.train(cfg, dataset={k: v.copy() for k, v in data.items()}, state_dim=S, action_dim=A,
                        max_action=1.0, logger=lambda d, step: logs.append((step, dict(d))), evaluate=evaluate,
@@ -198,3 +198,21 @@ def test_seed_tied_reward_models_give_every_seed_its_own_dataset(tmp_path):
     for k, tr in enumerate(both):
         solo = run(3 + k, 1)
         assert torch.equal(solo._params, tr._params), k
+
+
+def test_train_default_prep_gives_the_reference_normalised_states():
+    """train()'s default path z-scores on the device with numpy's statistics
+    (ref:132-139, 1438-1448): the buffer holds the reference's normalised states bit for bit."""
+    import iqlpref_amd as ia
+    from iqlpref_amd import prep
+    S, A, N = 17, 6, 5000
+    data = synth(N, S, A, seed=3)
+    buf = ia.ReplayBuffer(S, A, N, DEV)
+    mean, std = prep.prepare_replay({k: v.copy() for k, v in data.items()}, buf, env_name="halfcheetah-medium-v2",
+                                    normalize_reward=0, normalize=True, eps=1e-3, stats="host")
+    m, s = ia.compute_mean_std(data["observations"], 1e-3)
+    np.testing.assert_array_equal(mean, m)
+    np.testing.assert_array_equal(std, s)
+    np.testing.assert_array_equal(buf._states.cpu().numpy(), ia.normalize_states(data["observations"], m, s))
+    np.testing.assert_array_equal(buf._next_states.cpu().numpy(), ia.normalize_states(data["next_observations"], m, s))
+    np.testing.assert_array_equal(buf._rewards.cpu().numpy()[:, 0], data["rewards"])
