@@ -130,6 +130,19 @@ __device__ __forceinline__ void store4T(typename Prec<BF16>::T *dst, const float
   }
 }
 
+// IQL_WT_ACT (A/B build): the bf16 activations / deltas one kernel hands to the next leave
+// write-through (8-byte stores, lean bf16 paths only).
+#ifndef IQL_WT_ACT
+#define IQL_WT_ACT 0
+#endif
+__device__ __forceinline__ void act_store8(uint16_t *base, size_t elem, uint2 u) {
+#if IQL_WT_ACT
+  stg8_wt(base, (uint32_t)elem * 2u, u);
+#else
+  stg8(base + elem, u);
+#endif
+}
+
 // relu(round(acc + bias)) of the four batch rows a lane holds for one hidden unit (MFMA C layout),
 // in the compute type.  bf16: relu before the rounding (the same value: rounding is monotone and
 // keeps zero), two values per v_cvt_pk_bf16_f32, no round trip through f32 -- a third of the
@@ -634,8 +647,8 @@ __global__ __launch_bounds__(256, PRE ? 1 : 3) void k_forward(const TrainerDesc 
             hrow[0] = (T)(u.x & 0xffff), hrow[HP] = (T)(u.x >> 16);
             hrow[2 * HP] = (T)(u.y & 0xffff), hrow[3 * HP] = (T)(u.y >> 16);
             if (mine && row0 < B)
-              stg8(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 0) * H * BP +
-                       fidx<P>(col, row0 + 4 * q, BP / P::KM), u);
+              act_store8(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 0) * H * BP,
+                         fidx<P>(col, row0 + 4 * q, BP / P::KM), u);
           }
         }
         continue;
@@ -701,8 +714,8 @@ __global__ __launch_bounds__(256, PRE ? 1 : 3) void k_forward(const TrainerDesc 
             hrow[0] = (T)(u.x & 0xffff), hrow[HQP] = (T)(u.x >> 16);
             hrow[2 * HQP] = (T)(u.y & 0xffff), hrow[3 * HQP] = (T)(u.y >> 16);
             if (N.train_slot >= 0 && row0 < B)
-              stg8(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP +
-                       fidx<P>(col, row0 + 4 * q, BP / P::KM), u);
+              act_store8(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP,
+                         fidx<P>(col, row0 + 4 * q, BP / P::KM), u);
           }
         }
         continue;
@@ -1085,7 +1098,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
           T *drow = dz2s + (4 * g4) * HP + c2;
           drow[0] = (T)(u.x & 0xffff), drow[HP] = (T)(u.x >> 16);
           drow[2 * HP] = (T)(u.y & 0xffff), drow[3 * HP] = (T)(u.y >> 16);
-          if (mine) stg8(dst + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), u);
+          if (mine) act_store8(dst, fidx<P>(c2, slab * SLAB + 4 * g4, nkb), u);
         }
         continue;
       }
@@ -1132,8 +1145,8 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
         float t[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) t[i] = h1v[i] > 0.f ? acc[i] : 0.f;
-        stg8(g_dz1T + (size_t)net * H * BP + fidx<P>(col, slab * SLAB + 4 * q, nkb),
-             make_uint2(pk_bf16(t[0], t[1]), pk_bf16(t[2], t[3])));
+        act_store8(g_dz1T + (size_t)net * H * BP, fidx<P>(col, slab * SLAB + 4 * q, nkb),
+                   make_uint2(pk_bf16(t[0], t[1]), pk_bf16(t[2], t[3])));
       }
     } else {
       float outv[4];
