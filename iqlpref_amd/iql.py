@@ -752,6 +752,10 @@ class ImplicitQLearning:
     # -- checkpoints (ref:664-688) ------------------------------------------ #
     def state_dict(self) -> Dict[str, Any]:
         torch.cuda.synchronize(self._dev)
+        # (fresh views / step counters: whatever was done to the optimisers' state from outside, the
+        # checkpoint holds the arenas' moments and this trainer's step count)
+        if self.total_it > 0:  # (before the first step the optimisers hold no state, as the reference's)
+            self._bind_optimizer_state(rebuild=True)
         return {
             "qf": self.qf.state_dict(),
             "q_optimizer": self.q_optimizer.state_dict(),
