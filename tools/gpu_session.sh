@@ -38,6 +38,18 @@ print('agents', d.get('agents_per_gpu',{}).get('value'), 'ensemble', d.get('ense
         ROC_ACTIVE_WAIT_TIMEOUT=$w timeout -k 10 200 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-relabel --agents-per-gpu 0 --ensemble-q 0 2>/dev/null |
           python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('wait', $w, round(d['value']), d['ms_per_step'], d['timing']['ms_per_step_device'])" || exit 1
       done; done ;;
+    unrollscan)
+      # steps per hipGraph inside the driver's 20-step timed block: when does the GPU see its first packet
+      for round in 1 2; do for u in 20 10 5 4 2 1; do
+        timeout -k 10 200 python bench.py --gpus 1 --steps 20 --warmup 5 --unroll $u --no-cpu-baseline --no-relabel --agents-per-gpu 0 --ensemble-q 0 2>/dev/null |
+          python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('unroll', $u, round(d['value']), d['ms_per_step'], d['timing']['ms_per_step_device'])" || exit 1
+      done; done ;;
+    mlpscan)
+      # reward-MLP kernel: the product build against $EXTRA_LIBS
+      for lib in libiqlhip.so $EXTRA_LIBS; do
+        IQLHIP_LIB=$PWD/iqlpref_amd/$lib timeout -k 10 120 python tools/mlp_scan.py 2>&1 | grep -v "Dataset\|amdgpu.ids" >> $OUT/mlpscan.txt; rc=$?; stop_if_killed $rc mlpscan
+      done
+      cat $OUT/mlpscan.txt ;;
     ckpt)
       timeout -k 10 120 python tools/make_checkpoint.py $OUT/our_checkpoint.pt > $OUT/ckpt.log 2>&1; echo "ckpt rc=$?"; tail -2 $OUT/ckpt.log ;;
     groupscan)
