@@ -888,8 +888,11 @@ __device__ __forceinline__ void loss_terms(const TrainerDesc &D, int net, const 
 // phase for all H hidden units (dZ2 is the GEMM's K operand) and streams H x 64 of W2^T.
 // The parts share the stores: part p writes its 64 columns of dZ2, part 0 writes dZ3 and the
 // loss partial sums.
+// PW parts per work-group (1, 2 or 4; PW divides SPL): with the chip full anyway (seed groups) the
+// redundant loss / dZ2 phases are pure cost -- a work-group then owns PW x 64 columns of dZ1, every
+// wave PW n-tiles, and there are SPL / PW work-groups per (net, slab).  The same values either way.
 // ========================================================================
-template <bool BF16, int H, bool PRE>
+template <bool BF16, int H, bool PRE, int PW = 1>
 __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp, DevCtr *__restrict__ Cp,
                                               const int blk, char *smem, const int nslab, const int ntrain) {
   using K = KCfg<BF16, H>;
@@ -897,13 +900,15 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   using P = Prec<BF16>;
   using T = typename P::T;
   constexpr int SPL = C::SPL;
-  // Job j = SPL net + part lives on XCD j & 7, round j >> 3 (each L2 fetches only the part of
+  static_assert(SPL % PW == 0, "parts per work-group divide the parts");
+  constexpr int NPG = SPL / PW;  // part groups = work-groups per (net, slab)
+  // Job j = NPG net + part group lives on XCD j & 7, round j >> 3 (each L2 fetches only the part of
   // W2^T its work-groups stream).  (nslab, ntrain: preloaded kernel arguments, see k_forward)
   const TrainerDesc &D = *Dp;
   const int idx_ = blk >> 3;
   const int job = (idx_ / nslab) * 8 + (blk & 7), slab = idx_ % nslab;
-  const int net = job / SPL;
-  const int part = __builtin_amdgcn_readfirstlane(job % SPL);
+  const int net = job / NPG;
+  const int part = __builtin_amdgcn_readfirstlane(job % NPG);  // (the part GROUP: parts PW part .. + PW)
   if (net >= ntrain) return;
   // ---- ONE batch of scalar loads: everything the load phase needs, before any branch ----
   const int out_dim = D.net[net].out_dim, out_pad = D.net[net].out_pad;
@@ -921,7 +926,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   const int out_qt = D.out_qt, out_v = D.out_v, out_nv = D.out_nv, out_mean = D.out_mean, n_crit = D.E;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-uniform branches stay scalar
-  const int tile0 = part * 4 + wave;  // this wave's n-tile of dZ1 (of H / 16)
+  const int tile0 = part * PW * 4 + wave;  // this wave's first n-tile of dZ1 (of H / 16); the others: + 4 t
   const int r = lane & 15, q = lane >> 4;
   constexpr int HP = K::HP;
   const int nkb = BP / P::KM;
@@ -986,13 +991,17 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   __builtin_amdgcn_sched_barrier(0);
   // PRE: the operands of the closing GEMM are requested here, ahead of everything; otherwise
   // behind the dZ2 phase (fewer live registers, more work-groups per CU; A/B: IQLHIP_BWD_PRE)
-  uint4 w2t[K::NK2];
-  float h1v[4];
+  uint4 w2t[PW][K::NK2];
+  float h1v[PW][4];
   auto load_gemm_operands = [&]() {
-    const T *W2Tw = reinterpret_cast<const T *>(p_w2ct) + (size_t)tile0 * K::NK2 * 64 * P::EPV;
 #pragma unroll
-    for (int ks = 0; ks < K::NK2; ++ks) w2t[ks] = ldg16(W2Tw + ks * 64 * P::EPV + lane * P::EPV);
-    load4T<BF16>(g_hT + (size_t)(net * 2 + 0) * H * BP + fidx<P>(16 * tile0 + r, slab * SLAB + 4 * q, nkb), h1v);
+    for (int t = 0; t < PW; ++t) {
+      const T *W2Tw = reinterpret_cast<const T *>(p_w2ct) + (size_t)(tile0 + 4 * t) * K::NK2 * 64 * P::EPV;
+#pragma unroll
+      for (int ks = 0; ks < K::NK2; ++ks) w2t[t][ks] = ldg16(W2Tw + ks * 64 * P::EPV + lane * P::EPV);
+      load4T<BF16>(g_hT + (size_t)(net * 2 + 0) * H * BP + fidx<P>(16 * (tile0 + 4 * t) + r, slab * SLAB + 4 * q, nkb),
+                   h1v[t]);
+    }
   };
   if constexpr (PRE) load_gemm_operands();
   STAMP(1, 1);
@@ -1084,7 +1093,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
         }
       }
     }
-    const bool mine = c2 / C::HQ == part;  // the part that owns this hidden unit stores its dZ2
+    const bool mine = (c2 / C::HQ) / PW == part;  // the part (group) that owns this hidden unit stores its dZ2
     bool lean = false;
     if constexpr (BF16) lean = !drop_on;  // mask before the rounding (the same value), packed conversion
 #pragma unroll
@@ -1128,25 +1137,26 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     stg(g_lossp + net * nslab + slab, s);
   }
 
-  // ---- dZ1 = (dZ2 W2) * relu'(h1)   (MFMA, B operand = transposed copy; one n-tile per wave) ----
-  {
+  // ---- dZ1 = (dZ2 W2) * relu'(h1)   (MFMA, B operand = transposed copy; PW n-tiles per wave) ----
+#pragma unroll
+  for (int t = 0; t < PW; ++t) {
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     const T *xrow = dz2s + r * HP + P::EPV * q;
 #pragma unroll
     for (int ks = 0; ks < K::NK2; ++ks) {
       const uint4 a = *reinterpret_cast<const uint4 *>(xrow + ks * P::KM);
-      P::mma(a, w2t[ks], acc);
+      P::mma(a, w2t[t][ks], acc);
     }
-    const int col = 16 * tile0 + r;
+    const int col = 16 * (tile0 + 4 * t) + r;
     bool lean = false;
     if constexpr (BF16) lean = !drop_on;
     if (lean) {
       if constexpr (BF16) {
-        float t[4];
+        float tv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) t[i] = h1v[i] > 0.f ? acc[i] : 0.f;
+        for (int i = 0; i < 4; ++i) tv[i] = h1v[t][i] > 0.f ? acc[i] : 0.f;
         act_store8(g_dz1T + (size_t)net * H * BP, fidx<P>(col, slab * SLAB + 4 * q, nkb),
-                   make_uint2(pk_bf16(t[0], t[1]), pk_bf16(t[2], t[3])));
+                   make_uint2(pk_bf16(tv[0], tv[1]), pk_bf16(tv[2], tv[3])));
       }
     } else {
       float outv[4];
@@ -1154,7 +1164,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
       for (int i = 0; i < 4; ++i) {
         float s = P::round(acc[i]);
         if (drop_on) s = P::round(s * drop_scale);
-        outv[i] = h1v[i] > 0.f ? s : 0.f;
+        outv[i] = h1v[t][i] > 0.f ? s : 0.f;
       }
       store4T<BF16>(g_dz1T + (size_t)net * H * BP + fidx<P>(col, slab * SLAB + 4 * q, nkb), outv);
     }
@@ -1895,13 +1905,12 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 // ------------------------------------------------------------------------
 // __global__ wrappers
 // ------------------------------------------------------------------------
-template <bool BF16, int H, bool PRE>
-__global__ __launch_bounds__(256, PRE ? 1 : (BF16 ? 6 : 3)) void k_backward(const TrainerDesc *__restrict__ Dp,
-                                                                            const DevArgs *__restrict__ Ap,
-                                                                            DevCtr *__restrict__ Cp, const int nslab,
-                                                                            const int ntrain) {
+template <bool BF16, int H, bool PRE, int PW>
+__global__ __launch_bounds__(256, PRE ? 1 : (PW > 1 ? (BF16 ? 4 : 2) : (BF16 ? 6 : 3)))
+void k_backward(const TrainerDesc *__restrict__ Dp, const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
+                const int nslab, const int ntrain) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  backward_body<BF16, H, PRE>(Dp + blockIdx.y, Cp + blockIdx.y, (int)blockIdx.x, smem, nslab, ntrain);
+  backward_body<BF16, H, PRE, PW>(Dp + blockIdx.y, Cp + blockIdx.y, (int)blockIdx.x, smem, nslab, ntrain);
 }
 
 template <bool BF16, bool LAT>
@@ -2025,22 +2034,42 @@ hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD
 #undef LAUNCH_F
   return hipGetLastError();
 }
+// parts of the dZ1 columns per backward work-group: 1 for one seed at batch 256 (every part repeats
+// the loss / dZ2 phase: parallelism bought with redundant work), 2 from 512 rows per launch on.
+// Measured (tools/group_scan.py, IQLHIP_BWD_PW; steps/s with 1 / 2 parts per work-group): one seed
+// 65.4k / 64.1k, two seeds 97.4k / 102.2k, four 136.2k / 144.6k, eight 177.3k / 189.5k (k_backward 10.7 ->
+// 8.0 us); all four parts in one work-group (512 work-groups of 128 registers, spilling): 148k.
+int bwd_parts_per_wg(int B, int H, int n_seeds) {
+  static const int forced = getenv("IQLHIP_BWD_PW") ? atoi(getenv("IQLHIP_BWD_PW")) : 0;  // A/B knob
+  const int spl = layer2_parts(H);
+  if ((forced == 1 || forced == 2 || forced == 4) && spl % forced == 0) return forced;
+  return ((int64_t)B * n_seeds >= 512 && spl % 2 == 0) ? 2 : 1;
+}
 hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
                            DevCtr *c, int n_seeds, hipStream_t st) {
-  const int grid = 8 * ((layer2_parts(D.H) * D.ntrain + 7) / 8) * (D.B / SLAB);
+  const int pw = bwd_parts_per_wg(D.B, D.H, n_seeds);
+  const int grid = 8 * ((layer2_parts(D.H) / pw * D.ntrain + 7) / 8) * (D.B / SLAB);
   const size_t sm = bwd_smem_bytes(bf16, D.H);
   static const int forced_pre = getenv("IQLHIP_BWD_PRE") ? atoi(getenv("IQLHIP_BWD_PRE")) : -1;  // A/B knob
   // measured: no difference for one seed (63.2k either way), K = 8 170.2k against 165.1k
   const bool pre = forced_pre >= 0 ? forced_pre != 0 : (int64_t)D.B * n_seeds < 1024;
-#define CALL(BF, HH)                                                                                                     \
-  do {                                                                                                                   \
-    if (pre)                                                                                                             \
-      hipLaunchKernelGGL((k_backward<BF, HH, true>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain);  \
-    else                                                                                                                 \
-      hipLaunchKernelGGL((k_backward<BF, HH, false>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, D.ntrain); \
+#define LAUNCH_B(BF, HH, PRE_, PW_)                                                                          \
+  hipLaunchKernelGGL((k_backward<BF, HH, PRE_, PW_>), dim3(grid, n_seeds), dim3(256), sm, st, dD, a, c, D.B / SLAB, \
+                     D.ntrain)
+#define CALL(BF, HH)                                                  \
+  do {                                                                \
+    if constexpr (HH >= 256) {                                        \
+      if (pw == 4) { LAUNCH_B(BF, HH, false, 4); break; }             \
+    }                                                                 \
+    if constexpr (HH >= 128) {                                        \
+      if (pw == 2) { LAUNCH_B(BF, HH, false, 2); break; }             \
+    }                                                                 \
+    if (pre) LAUNCH_B(BF, HH, true, 1);                               \
+    else LAUNCH_B(BF, HH, false, 1);                                  \
   } while (0)
   DISPATCH_H(bf16, D.H, CALL);
 #undef CALL
+#undef LAUNCH_B
   return hipGetLastError();
 }
 hipError_t launch_stage(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,

@@ -50,6 +50,13 @@ print('agents', d.get('agents_per_gpu',{}).get('value'), 'ensemble', d.get('ense
         IQLHIP_LIB=$PWD/iqlpref_amd/$lib timeout -k 10 120 python tools/mlp_scan.py 2>&1 | grep -v "Dataset\|amdgpu.ids" >> $OUT/mlpscan.txt; rc=$?; stop_if_killed $rc mlpscan
       done
       cat $OUT/mlpscan.txt ;;
+    bwdpw)
+      # parts of the dZ1 columns per backward work-group in a group of 8 (and of 4, 2): IQLHIP_BWD_PW
+      for round in 1 2; do for pw in 1 2 4; do
+        echo "== IQLHIP_BWD_PW=$pw" >> $OUT/bwdpw.txt
+        IQLHIP_BWD_PW=$pw timeout -k 10 200 python tools/group_scan.py 8 4 2>&1 | grep -v "Dataset\|amdgpu.ids" >> $OUT/bwdpw.txt; rc=$?; stop_if_killed $rc bwdpw
+      done; done
+      cut -c1-260 $OUT/bwdpw.txt ;;
     ckpt)
       timeout -k 10 120 python tools/make_checkpoint.py $OUT/our_checkpoint.pt > $OUT/ckpt.log 2>&1; echo "ckpt rc=$?"; tail -2 $OUT/ckpt.log ;;
     groupscan)
