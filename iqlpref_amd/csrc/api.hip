@@ -481,13 +481,24 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   // (pointers are filled in after the workspace has been carved)
   std::vector<UpdItem> per_xcd[8];
   for (int n = 0; n < NT; ++n) {
-    // layer 2 (the H x H matrix, 32 tiles at H = 256) fills XCD 2n: every dZ^T / activation
-    // panel of that GEMM is then fetched into ONE L2; layers 1 and 3 go to XCD 2n+1
+    // Both XCDs of a network take half of EVERY layer's work (the upper / the lower half of the
+    // out-features; a one-tile-row output layer by in-feature tile parity).  The layer-2 tiles carry
+    // 87 % of the optimiser state: with all of them on the even XCDs (rounds 1-2: one L2 per GEMM's
+    // panels) four of the eight XCDs moved nearly all bytes of a launch -- no matter for one seed
+    // (65.8k steps/s either way), but 8 seeds per launch 190.0k -> 201.1k, 4 seeds 144.5k -> 154.3k
+    // (k_update 19.8 -> 17.6 us; IQLHIP_ITEM_BALANCE=0 builds the old table).  Moving an eighth of
+    // the critics' tiles (which also carry the targets) to the other networks' XCDs: +0.5 %, not taken.
+    static const bool balance = !(getenv("IQLHIP_ITEM_BALANCE") && atoi(getenv("IQLHIP_ITEM_BALANCE")) == 0);
     auto put = [&](int layer, int o0, int i0) {
       UpdItem it;
       memset(&it, 0, sizeof(it));
       it.net = n, it.layer = layer, it.o0 = o0, it.i0 = i0;
-      per_xcd[(2 * n + (layer == 1 ? 0 : 1)) & 7].push_back(it);
+      int x = 2 * n + (layer == 1 ? 0 : 1);
+      if (balance) {
+        const int rows = layer == 2 ? outpad[n] : H;
+        x = 2 * n + ((layer == 2 && rows <= 64) ? ((i0 / 32) & 1) : (o0 >= rows / 2 ? 1 : 0));
+      }
+      per_xcd[x & 7].push_back(it);
     };
     for (int o0 = 0; o0 < H; o0 += 64)
       for (int i0 = 0; i0 < H; i0 += 32) put(1, o0, i0);
@@ -495,8 +506,11 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
     for (int o0 = 0; o0 < outpad[n]; o0 += 64)
       for (int i0 = 0; i0 < H; i0 += 32) put(2, o0, i0);
   }
-  size_t depth = 0;
-  for (auto &v : per_xcd) depth = v.size() > depth ? v.size() : depth;
+  size_t depth = 0, n_real = 0;
+  for (auto &v : per_xcd) depth = v.size() > depth ? v.size() : depth, n_real += v.size();
+  // the slots the table's padding leaves idle gather the next step's batch (k_update); a table
+  // that happens to be full gets two more rows of slots for that
+  if (8 * depth - n_real < 16) depth += 2;
   std::vector<UpdItem> items;
   for (size_t d = 0; d < depth; ++d)
     for (int x = 0; x < 8; ++x) {

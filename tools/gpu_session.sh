@@ -57,6 +57,13 @@ print('agents', d.get('agents_per_gpu',{}).get('value'), 'ensemble', d.get('ense
         IQLHIP_BWD_PW=$pw timeout -k 10 200 python tools/group_scan.py 8 4 2>&1 | grep -v "Dataset\|amdgpu.ids" >> $OUT/bwdpw.txt; rc=$?; stop_if_killed $rc bwdpw
       done; done
       cut -c1-260 $OUT/bwdpw.txt ;;
+    envab)
+      # A/B of an environment knob ($ENVAB, values 0 / 1): one seed and groups of 2, 4, 8
+      for round in 1 2; do for v in ${ENVAB_VALUES:-0 1}; do
+        echo "== $ENVAB=$v" >> $OUT/envab.txt
+        env $ENVAB=$v timeout -k 10 300 python tools/group_scan.py 1 2 4 8 2>&1 | grep -v "Dataset\|amdgpu.ids" >> $OUT/envab.txt; rc=$?; stop_if_killed $rc envab
+      done; done
+      cut -c1-260 $OUT/envab.txt ;;
     ckpt)
       timeout -k 10 120 python tools/make_checkpoint.py $OUT/our_checkpoint.pt > $OUT/ckpt.log 2>&1; echo "ckpt rc=$?"; tail -2 $OUT/ckpt.log ;;
     groupscan)
