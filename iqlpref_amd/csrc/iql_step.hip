@@ -1297,6 +1297,27 @@ __device__ __forceinline__ void copy_store4(typename Prec<BF16>::T *base, size_t
   store4T<BF16>(base + elem, v);
 #endif
 }
+// eight consecutive k of one row of a fragment-major copy: ONE 16-byte store in bf16 (a lane's whole
+// fragment slot), two in fp32 (elem4: the index of the second four)
+template <bool BF16>
+__device__ __forceinline__ void copy_store8(typename Prec<BF16>::T *base, size_t elem, size_t elem4, const float v[8]) {
+  using P = Prec<BF16>;
+  if constexpr (BF16) {
+    uint4 u;
+    u.x = (uint32_t)P::from_f32(v[0]) | ((uint32_t)P::from_f32(v[1]) << 16);
+    u.y = (uint32_t)P::from_f32(v[2]) | ((uint32_t)P::from_f32(v[3]) << 16);
+    u.z = (uint32_t)P::from_f32(v[4]) | ((uint32_t)P::from_f32(v[5]) << 16);
+    u.w = (uint32_t)P::from_f32(v[6]) | ((uint32_t)P::from_f32(v[7]) << 16);
+#if IQL_WT_ALL
+    stg16_wt(base, (uint32_t)elem * 2u, __builtin_bit_cast(float4, u));
+#else
+    stg16(base + elem, __builtin_bit_cast(float4, u));
+#endif
+  } else {
+    copy_store4<BF16>(base, elem, v);
+    copy_store4<BF16>(base, elem4, v + 4);
+  }
+}
 __device__ __forceinline__ void state_store1(float *base, int64_t elem, float v) {
 #if IQL_WT_ALL
   stg4_wt(base, (uint32_t)elem * 4u, v);
@@ -1335,7 +1356,8 @@ constexpr int UNIT = UMAXI / 16; // in-feature tiles of a layer-1 strip, at most
 constexpr int USR = IQL_USR;     // rows of a layer-1 strip (16 or 32)
 constexpr int UOT = USR / 16;    // out-feature tiles of a strip
 constexpr int UPD_TILE = UTO * (UTI + 4) > USR * (UMAXI + 4) ? UTO * (UTI + 4) : USR * (UMAXI + 4);
-constexpr int UPD_LDS = UPD_TILE + USR * (UMAXI + 4);  // floats of LDS per update work-group (~18 KB)
+// (the second region: a strip's new target weights, or -- group launches -- a layer-2 tile's)
+constexpr int UPD_LDS = UPD_TILE + (UTO * (UTI + 4) > USR * (UMAXI + 4) ? UTO * (UTI + 4) : USR * (UMAXI + 4));  // floats (~18 KB)
 
 template <bool BF16, bool LAT, int UT>
 __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
@@ -1856,6 +1878,11 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     }
     // the new weights replace this thread's gradients in the tile (step 4 reads them transposed)
     if (L == 1) *reinterpret_cast<float4 *>(&tile[ol * ULD + tc4]) = make_float4(p[0], p[1], p[2], p[3]);
+    // group launches: also the new target weights -- step 4 writes every copy of a layer-2 tile from
+    // LDS, eight elements (16 bytes of bf16) per store instead of four
+    const bool copies_from_lds = !LAT && L == 1;
+    if (copies_from_lds && has_target)
+      *reinterpret_cast<float4 *>(&tile2[ol * ULD + tc4]) = make_float4(tv[0], tv[1], tv[2], tv[3]);
     if (o < Odim && i < Idim) {
       const int64_t e = it.off_w + (int64_t)o * Idim + i;
       const int64_t te = it.toff_w + (int64_t)o * Idim + i;
@@ -1865,8 +1892,10 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       if (g_grads) stg16(g_grads + e, make_float4(g[0], g[1], g[2], g[3]));
       if (has_target) state_store(g_target, te, make_float4(tv[0], tv[1], tv[2], tv[3]));
       // 4 consecutive k of one row are contiguous in the fragment-major copies
-      copy_store4<BF16>(wc, fidx<P>(o, i, nkw), p);
-      if (has_target) copy_store4<BF16>(tc, fidx<P>(o, i, nkw), tv);
+      if (!copies_from_lds) {
+        copy_store4<BF16>(wc, fidx<P>(o, i, nkw), p);
+        if (has_target) copy_store4<BF16>(tc, fidx<P>(o, i, nkw), tv);
+      }
       if (L == 2) {  // layer 3: the [H][Opad] transposed copy k_backward reads (one unit's weights to all outputs)
         T *w3t = reinterpret_cast<T *>(it.w3t);
 #pragma unroll
@@ -1888,6 +1917,34 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   // ---- 4. transposed compute copy of layer 2 for the backward GEMM: [in][out] ----
   if (L == 1) {
     __syncthreads();
+    if constexpr (!LAT) {
+      static_assert(LAT || (UT == 256 && UTO == 64 && UTI == 32), "one pass of 8-element stores covers the tile");
+      // [out][in] copies (and the targets'): thread -> row tid / 4, in-features 8 (tid % 4) .. + 7
+      {
+        const int ol = tid >> 2, c8 = (tid & 3) * 8;
+        const float4 a0 = *reinterpret_cast<const float4 *>(&tile[ol * ULD + c8]);
+        const float4 a1 = *reinterpret_cast<const float4 *>(&tile[ol * ULD + c8 + 4]);
+        const float pv8[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        copy_store8<BF16>(wc, fidx<P>(o0 + ol, i0 + c8, nkw), fidx<P>(o0 + ol, i0 + c8 + 4, nkw), pv8);
+        if (has_target) {
+          const float4 t0 = *reinterpret_cast<const float4 *>(&tile2[ol * ULD + c8]);
+          const float4 t1 = *reinterpret_cast<const float4 *>(&tile2[ol * ULD + c8 + 4]);
+          const float tv8[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+          copy_store8<BF16>(tc, fidx<P>(o0 + ol, i0 + c8, nkw), fidx<P>(o0 + ol, i0 + c8 + 4, nkw), tv8);
+        }
+      }
+      // [in][out] copy: thread -> in-feature i0 + (tid & 31), out-features o0 + 8 (tid >> 5) .. + 7
+      {
+        const int il = tid & (UTI - 1), o8 = (tid >> 5) * 8;
+        float pv8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pv8[k] = tile[(o8 + k) * ULD + il];
+        copy_store8<BF16>(reinterpret_cast<T *>(it.w2ct), fidx<P>(i0 + il, o0 + o8, H / P::KM),
+                          fidx<P>(i0 + il, o0 + o8 + 4, H / P::KM), pv8);
+      }
+      STAMP(2, 4);
+      return;
+    }
     // thread -> in-feature i0 + (tid & 31), out-features o0 + 4 (tid >> 5) .. +3 (+ UT / 8 per pass)
 #pragma unroll
     for (int ps = 0; ps < (UTO / 4) / (UT / UTI); ++ps) {
