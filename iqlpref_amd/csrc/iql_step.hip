@@ -448,7 +448,7 @@ struct FCfg {
 };
 
 template <bool BF16, int H, int MT, int PW, bool PRE>
-__global__ __launch_bounds__(256, PRE ? 1 : 3) void k_forward(const TrainerDesc *__restrict__ Dp,
+__global__ __launch_bounds__(256, PRE ? 1 : (MT >= 4 ? 2 : 3)) void k_forward(const TrainerDesc *__restrict__ Dp,
                                                  const DevArgs *__restrict__ Ap,
                                                  const DevCtr *__restrict__ Cp, const int nsl_,
                                                  const int nfwd_) {
@@ -2037,8 +2037,11 @@ size_t bwd_smem_bytes(bool bf16, int H) {
 // work-group (K = 8: 154.8k steps/s against 150.2k with 64 rows x one part, 139.7k with 32 x one).
 int fwd_row_tiles(int B, int n_seeds) {
   static const int forced = getenv("IQLHIP_FWD_MT") ? atoi(getenv("IQLHIP_FWD_MT")) : 0;  // A/B knob
-  if ((forced == 1 || forced == 2) && B % (16 * forced) == 0) return forced;
+  if ((forced == 1 || forced == 2 || forced == 4) && B % (16 * forced) == 0) return forced;
   const int64_t rows = (int64_t)B * n_seeds;
+  // (round 3, on the balanced update table: 64-row work-groups pay from eight seeds per launch on --
+  // K = 8 202.5k -> 205.7k steps/s, k_forward 9.5 -> 9.05 us; K = 4 152.9k -> 147.1k, K = 2 103.7k -> 98.6k)
+  if (rows >= 2048 && B % 64 == 0) return 4;
   if (rows >= 512 && B % 32 == 0) return 2;
   return 1;
 }
@@ -2078,12 +2081,14 @@ hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD
   do {                                                                 \
     if constexpr (HH >= 128) {                                         \
       if (pw == 2) {                                                   \
-        if (mt == 2) LAUNCH_F(BF, HH, 2, 2);                           \
+        if (mt == 4) LAUNCH_F(BF, HH, 4, 2);                           \
+        else if (mt == 2) LAUNCH_F(BF, HH, 2, 2);                      \
         else LAUNCH_F(BF, HH, 1, 2);                                   \
         break;                                                         \
       }                                                                \
     }                                                                  \
-    if (mt == 2) LAUNCH_F(BF, HH, 2, 1);                               \
+    if (mt == 4) LAUNCH_F(BF, HH, 4, 1);                               \
+    else if (mt == 2) LAUNCH_F(BF, HH, 2, 1);                          \
     else LAUNCH_F(BF, HH, 1, 1);                                       \
   } while (0)
   DISPATCH_H(bf16, D.H, CALL);
