@@ -455,6 +455,30 @@ def test_seed_group_matches_separate_runs(gh, mode):
     np.testing.assert_array_equal(solo, alone[1].train_steps(buf, 5, B, graph_unroll=2).cpu().numpy())
 
 
+@pytest.mark.parametrize("mode,n_seeds", [("group", 8), ("group", 2), ("split", 8)])
+def test_seed_group_at_headline_shapes(gh, mode, n_seeds):
+    """The launch geometries that only large launches take -- two parts of the dZ1 columns per backward
+    work-group (from 512 rows per launch), two layer-2 parts and 32 / 64 rows per forward work-group
+    (from 512 / 2048 rows), the group variant of the update kernel with its copies written from LDS --
+    at H = 256, batch 256: every seed of the group = the same seed alone, bit for bit."""
+    import iqlpref_amd as ia
+    d, hyper, data, nets = helpers.load_traj("traj_antmaze_h256", "bf16")
+    B = hyper["batch"]
+    assert B * n_seeds >= 512 and hyper["hidden"] == 256
+    buf = gh.make_buffer(hyper, data)
+    seeds = tuple(range(11, 11 + n_seeds))
+    alone = [gh.make_trainer(hyper, nets, "bf16", seed=s) for s in seeds]
+    want = [t.train_steps(buf, 12, B, graph_unroll=4).cpu().numpy() for t in alone]
+    group = ia.SeedGroup([gh.make_trainer(hyper, nets, "bf16", seed=s) for s in seeds], chunk=8, mode=mode)
+    got = group.train_steps(buf, 12, B, return_losses=True, graph_unroll=4)
+    group.synchronize()
+    for w, g, ta, tg in zip(want, got, alone, group.trainers):
+        np.testing.assert_array_equal(w, g.cpu().numpy())
+        assert torch.equal(ta._params, tg._params) and torch.equal(ta._target, tg._target)
+        assert torch.equal(ta._exp_avg, tg._exp_avg) and torch.equal(ta._exp_avg_sq, tg._exp_avg_sq)
+    group.close()
+
+
 def test_seed_group_split_uneven_and_cu_slice_streams(gh):
     """mode="split" with three seeds (sub-groups of two and one) on the CU-slice streams, driven
     with per-seed injected indices: bit-identical to the seeds alone.  The C entry point refuses
