@@ -349,10 +349,8 @@ __global__ __launch_bounds__(64 * PT_WAVES, 4) void k_pt_relabel(const iqlhip_pt
     int len, t0;  // t0: timestep of the window's first transition
     load_window(win, start, len, t0);
     const int nmt = (len + 15) >> 4;           // 16-token tiles per kind
-    // the query: per lane the components that meet its key features 16 mt + 4 q + i
-    f32x4 qv[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) qv[mt] = *reinterpret_cast<const f32x4 *>(qbuf + qb * E + 16 * mt + 4 * q);
+    // (the query -- per lane the components that meet its key features 16 mt + 4 q + i -- is read from
+    // LDS where a job needs it: 16 registers that are not live across the two GEMMs of a job)
     // lane-local online softmax over the lane's tokens: running max, sum and weighted values per
     // m-tile.  The head of features 16 mt + 4 q + i is (16 mt) / HD for HD >= 16, 2 mt + (q >> 1) for
     // HD = 8, 4 mt + q for HD = 4: after the reductions below s[mt] is that head's logit.
@@ -364,45 +362,51 @@ __global__ __launch_bounds__(64 * PT_WAVES, 4) void k_pt_relabel(const iqlhip_pt
     for (int job = wave; job < 2 * nmt; job += PT_WAVES) {
       const int kind = job >= nmt ? 1 : 0;  // 0: state tokens, 1: action tokens
       const int mt_ = kind ? job - nmt : job;
-      f32x4 kvt[8];
+      // K^T = Wk . H^T + bias (h IS the B operand), the logits, THEN V^T = Wv . H^T + bias and the
+      // softmax update: keys and values are never live together (16 registers less at the peak: the
+      // kernel runs four waves per SIMD on 128 registers).  200k antmaze windows 11.69 -> 11.35 ms.
+      // (Tried on top: the next job's dataset rows requested one job ahead, also across the window
+      // barrier -- 12 more registers in flight: 83 spilled registers, 12.34 ms.)
+      f32x4 h[4];
       {
-        f32x4 x[4], h[4];
+        f32x4 x[4];
         embed_ln(kind, mt_, start, len, t0, x, h);
-        // K^T | V^T = Wkv . H^T + bias: h IS the B operand; keys (half 0) then values (half 1):
-        // four m-tiles at a time bound the live A fragments; component-major issue order
+      }
+      auto project = [&](const int half, f32x4 (&out)[4]) {
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-          const float4 bb = *reinterpret_cast<const float4 *>(fvec + 6 * E + 16 * mt + 4 * q);
-          kvt[mt] = f32x4{bb.x, bb.y, bb.z, bb.w};
+        for (int mt = 0; mt < 4; ++mt) {
+          const float4 bb = *reinterpret_cast<const float4 *>(fvec + 6 * E + 16 * (4 * half + mt) + 4 * q);
+          out[mt] = f32x4{bb.x, bb.y, bb.z, bb.w};
         }
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int ks = 0; ks < 4; ++ks) {
+          float4 wa[4];  // four m-tiles at a time bound the live A fragments; component-major issue order
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            float4 wa[4];
+          for (int mt = 0; mt < 4; ++mt)
+            wa[mt] = *reinterpret_cast<const float4 *>(wkvF + ((4 * (4 * half + mt) + ks) * 64 + lane) * 4);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-              wa[mt] = *reinterpret_cast<const float4 *>(wkvF + ((4 * (4 * half + mt) + ks) * 64 + lane) * 4);
+          for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-#pragma unroll
-              for (int mt = 0; mt < 4; ++mt) {
-                const float wc[4] = {wa[mt].x, wa[mt].y, wa[mt].z, wa[mt].w};
-                kvt[4 * half + mt] =
-                    __builtin_amdgcn_mfma_f32_16x16x4f32(wc[c], h[ks][c], kvt[4 * half + mt], 0, 0, 0);
-              }
+            for (int mt = 0; mt < 4; ++mt) {
+              const float wc[4] = {wa[mt].x, wa[mt].y, wa[mt].z, wa[mt].w};
+              out[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[c], h[ks][c], out[mt], 0, 0, 0);
             }
           }
         }
-      }
+      };
       // ---- this token's logits: bf16 q . bf16 k per head (exact products, fp32 sums), rounded to
       // bf16, scaled, rounded (ops.py:74-79) ----
       float s[4];
+      {
+        f32x4 kt[4];
+        project(0, kt);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        float p = qv[mt][0] * rbf(kvt[mt][0]);
-        p = fmaf(qv[mt][1], rbf(kvt[mt][1]), p), p = fmaf(qv[mt][2], rbf(kvt[mt][2]), p);
-        s[mt] = fmaf(qv[mt][3], rbf(kvt[mt][3]), p);
+        for (int mt = 0; mt < 4; ++mt) {
+          const f32x4 qv = *reinterpret_cast<const f32x4 *>(qbuf + qb * E + 16 * mt + 4 * q);
+          float p = qv[0] * rbf(kt[mt][0]);
+          p = fmaf(qv[1], rbf(kt[mt][1]), p), p = fmaf(qv[2], rbf(kt[mt][2]), p);
+          s[mt] = fmaf(qv[3], rbf(kt[mt][3]), p);
+        }
       }
       if (HD >= 16) {
 #pragma unroll
@@ -418,6 +422,8 @@ __global__ __launch_bounds__(64 * PT_WAVES, 4) void k_pt_relabel(const iqlhip_pt
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) s[mt] = xor16_sum(s[mt]);
       }
+      f32x4 vt[4];
+      project(1, vt);
       if (16 * mt_ + r < len) {  // (tokens past the window do not exist)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(64 * PT_WAVES, 4) void k_pt_relabel(const iqlhip_pt
           const float c_old = __expf(m_run[mt] - mn), pw = __expf(sc - mn);
           l_run[mt] = l_run[mt] * c_old + pw;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) o_run[mt][i] = o_run[mt][i] * c_old + pw * kvt[4 + mt][i];
+          for (int i = 0; i < 4; ++i) o_run[mt][i] = o_run[mt][i] * c_old + pw * vt[mt][i];
           m_run[mt] = mn;
         }
       }
