@@ -2039,9 +2039,9 @@ int fwd_row_tiles(int B, int n_seeds) {
   static const int forced = getenv("IQLHIP_FWD_MT") ? atoi(getenv("IQLHIP_FWD_MT")) : 0;  // A/B knob
   if ((forced == 1 || forced == 2 || forced == 4) && B % (16 * forced) == 0) return forced;
   const int64_t rows = (int64_t)B * n_seeds;
-  // (round 3, on the balanced update table: 64-row work-groups pay from eight seeds per launch on --
-  // K = 8 202.5k -> 205.7k steps/s, k_forward 9.5 -> 9.05 us; K = 4 152.9k -> 147.1k, K = 2 103.7k -> 98.6k)
-  if (rows >= 2048 && B % 64 == 0) return 4;
+  // (round 3, on the balanced update table: 64-row work-groups -- IQLHIP_FWD_MT=4 -- gain 1.6 % for eight
+  // seeds as ONE group, 202.5k -> 205.7k steps/s, and lose for everything else: K = 4 152.9k -> 147.1k,
+  // K = 2 103.7k -> 98.6k, two sub-groups of eight on two streams 263.5k -> 255.4k: not the default)
   if (rows >= 512 && B % 32 == 0) return 2;
   return 1;
 }
