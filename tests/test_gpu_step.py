@@ -458,8 +458,8 @@ def test_seed_group_matches_separate_runs(gh, mode):
 @pytest.mark.parametrize("mode,n_seeds", [("group", 8), ("group", 2), ("split", 8)])
 def test_seed_group_at_headline_shapes(gh, mode, n_seeds):
     """The launch geometries that only large launches take -- two parts of the dZ1 columns per backward
-    work-group (from 512 rows per launch), two layer-2 parts and 32 / 64 rows per forward work-group
-    (from 512 / 2048 rows), the group variant of the update kernel with its copies written from LDS --
+    work-group (from 512 rows per launch), two layer-2 parts and 32 rows per forward work-group
+    (from 1024 / 512 rows), the group variant of the update kernel with its copies written from LDS --
     at H = 256, batch 256: every seed of the group = the same seed alone, bit for bit."""
     import iqlpref_amd as ia
     d, hyper, data, nets = helpers.load_traj("traj_antmaze_h256", "bf16")
