@@ -4,10 +4,10 @@
 // S=500, N=1M) -- here it stays in HBM.  One work-group copies COLS >= 32 columns (128-byte row
 // segments: whole HBM lines) into LDS as order-preserving integer keys, column-major, and L
 // consecutive lanes share a column (L ~ S / 16: 2 lanes at S = 20, 32 lanes = 1024-thread
-// work-groups at S = 500): the n_tail-th smallest key is found by a 32-step bisection (exact, no sort) in which
+// work-groups at S = 500): the n_tail-th smallest key is found by counting passes (exact, no sort) in which
 // every lane counts its quarter-rows with 16-byte LDS reads and the L counts meet in log2(L)
-// shuffles; ties at the threshold are counted, so the sum equals the partition-based mean up to
-// fp32 summation order.  HBM traffic: 4 S bytes per column, read once, in COLS * 4 byte row
+// shuffles (the probes: see below); ties at the threshold are counted, so the sum equals the
+// partition-based mean up to fp32 summation order.  HBM traffic: 4 S bytes per column, read once, in COLS * 4 byte row
 // segments.  LDS rows are padded so that 16-byte reads of neighbouring columns hit disjoint banks.
 #include "../../include/iqlhip.h"
 #include "common.h"
@@ -89,22 +89,85 @@ __global__ __launch_bounds__(COLS *L) void k_cvar(const float *__restrict__ pred
     if (p == 0 && col0 + c < N) out[col0 + c] = sum / (float)n_tail;
     return;
   }
-  // smallest key t such that #(keys <= t) >= n_tail  == the n_tail-th smallest key
-  uint32_t lo = 0u, hi = 0xffffffffu;
+  // The n_tail-th smallest key t = the smallest t with #(keys <= t) >= n_tail, found exactly and
+  // without sorting.  Invariant: t in [lo, hi], c_lo = #(keys < lo) < n_tail <= c_hi = #(keys <= hi).
+  // One pass finds the column's minimum and maximum (the bracket); then counting passes shrink it,
+  // the probe taken in turn where a linear interpolation of the counts between the bracket's VALUES
+  // puts the rank, at the middle of the value range (ensemble predictions of one transition are a
+  // smooth sample: a few passes bring the bracket down to a handful of elements) and at the middle
+  // of the key range (the guarantee: at most 96 passes); a
+  // bracket of <= BR elements is finished by taking its distinct minima one at a time: ~8 + 3 passes
+  // for 25 of 500 normal samples instead of the 32 of a bisection over all 2^32 keys (round 2): 2.7 ->
+  // 2.05 ms at S = 500, N = 1M.  What remains is the copy into LDS: 128-byte pieces of 500 rows 4 MB
+  // apart (a TLB entry per row and work-group); requesting four rows per thread at once did not move it.
+  constexpr int BR = 8;
+  uint32_t lo, hi;
+  {
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    for (int k = 4 * p; k < S4; k += 4 * L) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(col + k);
+      const uint32_t kk[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        mn = min(mn, kk[e]);
+        if (k + e < S) mx = max(mx, kk[e]);  // (rows S .. hold the padding key 0xffffffff)
+      }
+    }
+    lo = lane_min_u32<L>(mn), hi = ~lane_min_u32<L>(~mx);
+  }
+  int c_lo = 0, c_hi = S;
 #pragma unroll 1
-  for (int it = 0; it < 32; ++it) {
-    const uint32_t mid = lo + ((hi - lo) >> 1);
+  for (int it = 0, ph = 0; it < 100 && lo < hi && c_hi - c_lo > BR; ++it, ph = ph == 2 ? 0 : ph + 1) {
+    const uint32_t span = hi - lo;  // >= 1; the probe lies in [lo, hi - 1]
+    uint32_t mid = lo + (span >> 1);  // ph == 2: the middle of the KEY range (the guarantee)
+    if (ph < 2) {
+      // ph == 0: where a linear interpolation of the counts between the bracket's VALUES puts the rank;
+      // ph == 1: the middle of the VALUE range (one-sided interpolation steps stall on a convex
+      // distribution tail; the keys of floats around zero are almost all of the key range and hold
+      // almost none of the data)
+      const float frac = ph == 0 ? ((float)(n_tail - c_lo) - 0.5f) / (float)(c_hi - c_lo) : 0.5f;
+      const float lv = key2f(lo), hv = key2f(hi);
+      const float mv = lv + (hv - lv) * frac;
+      if (mv >= lv && mv <= hv) {  // (false for NaN / overflowing brackets: the key midpoint then)
+        const uint32_t mk = f2key(mv);
+        mid = mk < lo ? lo : (mk >= hi ? hi - 1u : mk);
+      }
+    }
     int cnt = 0;
     for (int k = 4 * p; k < S4; k += 4 * L) {
       const uint4 v = *reinterpret_cast<const uint4 *>(col + k);
       cnt += (v.x <= mid ? 1 : 0) + (v.y <= mid ? 1 : 0) + (v.z <= mid ? 1 : 0) + (v.w <= mid ? 1 : 0);
     }
     cnt = lane_sum<L>(cnt);
-    if (lo < hi) {
-      if (cnt >= n_tail)
-        hi = mid;
-      else
-        lo = mid + 1u;
+    if (cnt >= n_tail)
+      hi = mid, c_hi = cnt;
+    else
+      lo = mid + 1u, c_lo = cnt;
+  }
+  if (lo < hi) {
+    // a handful of elements in [lo, hi]: the (n_tail - c_lo)-th smallest of them, one distinct minimum
+    // (with its multiplicity) per pass -- at most BR passes
+    int need = n_tail - c_lo;  // >= 1
+#pragma unroll 1
+    for (int it = 0; it <= BR && need > 0; ++it) {
+      uint32_t lm = 0xffffffffu;
+      int lc = 0;
+      for (int k = 4 * p; k < S4; k += 4 * L) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(col + k);
+        const uint32_t kk[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (kk[e] >= lo) {
+            lc = kk[e] < lm ? 1 : (kk[e] == lm ? lc + 1 : lc);
+            lm = min(lm, kk[e]);
+          }
+        }
+      }
+      const uint32_t gm = lane_min_u32<L>(lm);
+      const int gc = lane_sum<L>(lm == gm ? lc : 0);
+      need -= gc;
+      if (need > 0) lo = gm + 1u;  // (gm < hi here: the bracket still holds the rank)
+      else lo = gm;
     }
   }
   const float thr = key2f(lo);
