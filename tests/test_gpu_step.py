@@ -355,6 +355,8 @@ def test_errors(gh):
 @pytest.mark.parametrize("S,A,H,B,det,drop,E", [
     (29, 8, 256, 1024, False, None, 2), (45, 24, 256, 256, False, 0.1, 2),
     (17, 6, 128, 48, True, None, 2), (11, 3, 64, 16, False, None, 2),
+    # (two parts per backward work-group -- from 512 rows per launch on -- where H = 128 has only two)
+    (17, 6, 128, 512, False, None, 2), (11, 3, 64, 512, True, None, 2),
     # BASELINE config 5: E-way critic ensemble (no reference implementation: the oracle's E-way
     # generalisation of ref:595-613 is the checker, pinned to the reference at E = 2 only)
     (29, 8, 256, 1024, False, None, 4), (29, 8, 256, 256, False, None, 3), (17, 6, 128, 48, True, None, 8),
