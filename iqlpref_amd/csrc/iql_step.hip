@@ -2148,11 +2148,22 @@ hipError_t launch_update(bool bf16, const TrainerDesc *dD, const DevArgs *a, Dev
                          const UpdItem *items, int n_items, int n_seeds, hipStream_t st) {
   // n_items tiles + the misc block; a group launch pads grid.x to a multiple of 8
   const dim3 grid(n_seeds > 1 ? round_up(n_items + 1, 8) : n_items + 1, n_seeds);
-  if (bf16 && n_seeds > 1)
+  // The 512-thread latency variant while a lone seed's work-groups have a CU each; the four-per-CU
+  // throughput variant for groups and for a seed with more work items than CUs (E = 4 critics at batch
+  // 1024: 337 items, 30.7k -> 32.0k steps/s; two critics at batch 256: 65.7k -> 63.5k).  The same bits.
+  static const int forced_lat = getenv("IQLHIP_UPD_LAT") ? atoi(getenv("IQLHIP_UPD_LAT")) : -1;  // A/B knob
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      n = 256;
+    return n;
+  }();
+  const bool lat = forced_lat >= 0 ? forced_lat != 0 : (n_seeds == 1 && n_items + 1 <= cus + 1);
+  if (bf16 && !lat)
     hipLaunchKernelGGL((k_update<true, false>), grid, dim3(256), 0, st, dD, a, c, items, n_items);
   else if (bf16)
     hipLaunchKernelGGL((k_update<true, true>), grid, dim3(512), 0, st, dD, a, c, items, n_items);
-  else if (n_seeds > 1)
+  else if (!lat)
     hipLaunchKernelGGL((k_update<false, false>), grid, dim3(256), 0, st, dD, a, c, items, n_items);
   else
     hipLaunchKernelGGL((k_update<false, true>), grid, dim3(512), 0, st, dD, a, c, items, n_items);
