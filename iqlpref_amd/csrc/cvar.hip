@@ -38,6 +38,13 @@ __device__ __forceinline__ uint32_t lane_min_u32(uint32_t v) {
   return v;
 }
 
+// Row k of column c lives at LDS word c SP + (k ^ swz(c)): the copy writes one row of 32 columns
+// per half-wave, i.e. words SP apart -- with SP = 32 (mod 64) only TWO banks without the swizzle (a
+// 16-way conflict on every store of the copy); the mask spreads them over 8 x 2 banks.  It is a
+// multiple of 4 below 32: a 16-byte read of four consecutive rows stays one aligned 16-byte read, and
+// a row never leaves its 32-word block (SP is a multiple of 32).
+__device__ __forceinline__ int swz(int c) { return 4 * ((c >> 1) & 7); }
+
 constexpr int SMALL_TAIL = 8;  // up to this many tail elements are taken one distinct minimum at a time
 
 // COLS columns per work-group, L consecutive lanes per column (COLS * L threads)
@@ -52,11 +59,12 @@ __global__ __launch_bounds__(COLS *L) void k_cvar(const float *__restrict__ pred
     const int c = tid % COLS;
     const bool on = col0 + c < N;
     for (int k = tid / COLS; k < SP; k += L)  // (COLS * L threads: L rows per pass)
-      keys[c * SP + k] = (k < S && on) ? f2key(ldg(preds + (size_t)k * N + col0 + c)) : 0xffffffffu;
+      keys[c * SP + (k ^ swz(c))] = (k < S && on) ? f2key(ldg(preds + (size_t)k * N + col0 + c)) : 0xffffffffu;
   }
   __syncthreads();
   const int c = tid / L, p = tid % L;
   const uint32_t *col = keys + c * SP;
+  const int sw = swz(c);  // (k below is a multiple of 4: the four keys of a 16-byte read stay together)
   const int S4 = round_up(S, 4);  // (keys beyond S compare greater than every threshold below 2^32 - 1)
   if (n_tail <= SMALL_TAIL) {
     // ---- short tails (n_tail = 1 is the snapshot ensemble of ref:1152 at S = 20: the minimum):
@@ -70,7 +78,7 @@ __global__ __launch_bounds__(COLS *L) void k_cvar(const float *__restrict__ pred
       uint32_t lm = 0xffffffffu;
       int lc = 0;
       for (int k = 4 * p; k < S4; k += 4 * L) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(col + k);
+        const uint4 v = *reinterpret_cast<const uint4 *>(col + (k ^ sw));
         const uint32_t kk[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(COLS *L) void k_cvar(const float *__restrict__ pred
   {
     uint32_t mn = 0xffffffffu, mx = 0u;
     for (int k = 4 * p; k < S4; k += 4 * L) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(col + k);
+      const uint4 v = *reinterpret_cast<const uint4 *>(col + (k ^ sw));
       const uint32_t kk[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(COLS *L) void k_cvar(const float *__restrict__ pred
     }
     int cnt = 0;
     for (int k = 4 * p; k < S4; k += 4 * L) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(col + k);
+      const uint4 v = *reinterpret_cast<const uint4 *>(col + (k ^ sw));
       cnt += (v.x <= mid ? 1 : 0) + (v.y <= mid ? 1 : 0) + (v.z <= mid ? 1 : 0) + (v.w <= mid ? 1 : 0);
     }
     cnt = lane_sum<L>(cnt);
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(COLS *L) void k_cvar(const float *__restrict__ pred
       uint32_t lm = 0xffffffffu;
       int lc = 0;
       for (int k = 4 * p; k < S4; k += 4 * L) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(col + k);
+        const uint4 v = *reinterpret_cast<const uint4 *>(col + (k ^ sw));
         const uint32_t kk[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(COLS *L) void k_cvar(const float *__restrict__ pred
   float sum = 0.f;
   int less = 0;
   for (int k = 4 * p; k < S4; k += 4 * L) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(col + k);
+    const uint4 v = *reinterpret_cast<const uint4 *>(col + (k ^ sw));
     const uint32_t kk[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e)
