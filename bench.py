@@ -14,9 +14,12 @@ the all-gather of the per-rank metric record).  Rank 0 prints ONE JSON line.
 processes itself (one per GPU, RCCL), before anything touches a GPU -- the
 reference's process-per-GPU model (ensemble_sweeps/launch.sh:84-94).
 
-Timing: W untimed warm-up steps, then blocks of EXACTLY K steps, each replayed
-as one hipGraph of K steps (unroll = min(--unroll, K)) and bracketed by
-barrier + synchronize on both sides.  The block is repeated until >= 0.25 s of
+Timing: W untimed warm-up steps, then blocks of EXACTLY K steps -- plain kernel
+launches from the library's C loop (the default; hipGraphs of --unroll steps on
+request: every graph launch costs ~5 us of device time that back-to-back kernels
+do not, and the GPU starts with the first launch instead of behind the host's
+work for a 60-node graph: 318-322 us against 322-325 us per 20-step block) --
+bracketed by barrier + synchronize on both sides.  The block is repeated until >= 0.25 s of
 timed work has accumulated; `ms_per_step` is the median block (max over ranks)
 divided by K, `value` = N * K / that block time.
 """
@@ -159,7 +162,11 @@ def main():
     ap.add_argument("--steps", type=int, default=50_000)
     ap.add_argument("--warmup", type=int, default=5_000)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--unroll", type=int, default=50, help="steps per hipGraph (clamped to --steps)")
+    ap.add_argument("--unroll", type=int, default=0,
+                    help="steps per hipGraph; 0 (the default, and any block of fewer steps) = plain kernel launches "
+                         "from the library's C loop, the faster mode for one seed (66.9k against 66.1k steps/s with "
+                         "graphs of 50 steps; 20-step blocks 62.6k against 61.7k as one graph); "
+                         "negative: ONE graph of min(-unroll, steps) steps (the round-2 behaviour, for A/B)")
     ap.add_argument("--min-timed-s", type=float, default=0.25,
                     help="the K-step block is repeated until this much timed work has accumulated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -213,8 +220,11 @@ def main():
     buf.load_d4rl_dataset(data)
     tr = build_trainer(ia, torch, device, seed, args.precision)
     K = args.steps
-    unroll = max(1, min(args.unroll, K))
-    chunk = max(unroll, 20_000 // unroll * unroll)
+    if args.unroll < 0:
+        unroll = max(1, min(-args.unroll, K))
+    else:
+        unroll = args.unroll if 0 < args.unroll <= K else 0  # 0: plain launches
+    chunk = 20_000 if unroll == 0 else max(unroll, 20_000 // unroll * unroll)
 
     def run(n):
         done = 0
@@ -318,7 +328,8 @@ def main():
             "config": {"workload": "IQL antmaze-medium-diverse-v2 shapes (S=29 A=8 H=256), "
                                    "1M-transition device replay, batch 256, one seed per GPU",
                        "batch": BATCH, "buffer_rows": N_ROWS, "graph_unroll": unroll,
-                       "graph_launches_per_block": K // unroll, "eager_steps_per_block": K % unroll},
+                       "graph_launches_per_block": K // unroll if unroll else 0,
+                       "eager_steps_per_block": K % unroll if unroll else K},
             "timing": {"reps": reps, "timed_steps_total": reps * K,
                        "block_ms": {"median": dt_med * 1e3, "min": float(blk[0]) * 1e3,
                                     "max": float(blk[-1]) * 1e3},
@@ -348,13 +359,13 @@ def main():
             out["ranks"] = recs
         if world == 1 and K < 5_000 and not args.no_sustained:
             # the same path sustained over a long region, for comparison with the K-step blocks
-            n_long = 20_000 // unroll * unroll
+            n_long = 20_000 // unroll * unroll if unroll else 20_000
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             run(n_long)
             torch.cuda.synchronize()
             out["sustained"] = {"steps": n_long, "value": n_long / (time.perf_counter() - t1), "unit": "steps/s",
-                                "note": "one timed region of this many steps, same graphs; not `value`"}
+                                "note": "one timed region of this many steps, same launch mode; not `value`"}
         # (secondary legs: none of them may take the headline record down with it)
         if world == 1 and args.agents_per_gpu > 1:
             try:

@@ -173,7 +173,8 @@ class SeedGroup:
         any_idx, any_keep = any(t is not None for t in idx), any(t is not None for t in keep)
         for t in self.trainers:
             t._refresh_lrs()
-        unroll = self.trainers[0]._graph_unroll if graph_unroll is None else graph_unroll
+        # (group launches: graphs of 50 steps 202-204k steps/s for 8 seeds, plain launches 198-200k)
+        unroll = 50 if graph_unroll is None else graph_unroll
         with torch.cuda.device(self._dev):
             check(self._lib.iqlhip_group_train_steps(
                 self._group, views, n_steps, parr(idx) if any_idx else None,
@@ -193,10 +194,11 @@ class SeedGroup:
             c = min(self._chunk, n_steps - done)
             for k, (tr, st, buf) in enumerate(zip(self.trainers, self._streams, bufs)):
                 with torch.cuda.stream(st):
+                    # (one host thread feeds every stream: graphs keep its share per step small)
                     r = tr.train_steps(buf, c, batch_size, return_losses=return_losses,
                                        indices=None if idx[k] is None else idx[k][done:done + c],
                                        dropout_keep=None if keep[k] is None else keep[k][done:done + c],
-                                       graph_unroll=graph_unroll)
+                                       graph_unroll=8 if graph_unroll is None else graph_unroll)
                     if return_losses:
                         out[k].append(r)
             done += c

@@ -21,10 +21,10 @@ for K in ks:
     trs = [bench.build_trainer(ia, torch, dev, 10 + i, "bf16") for i in range(K)]
     g = ia.SeedGroup(trs, mode="group")
     n = int(os.environ.get("GROUP_SCAN_STEPS", "10000"))  # (short regions for rocprofv3 --pmc passes)
-    g.train_steps(buf, min(1000, n), bench.BATCH, graph_unroll=50)
+    g.train_steps(buf, min(1000, n), bench.BATCH, graph_unroll=int(os.environ.get('GS_UNROLL', '50')))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    g.train_steps(buf, n, bench.BATCH, graph_unroll=50)
+    g.train_steps(buf, n, bench.BATCH, graph_unroll=int(os.environ.get('GS_UNROLL', '50')))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kt = g.kernel_times(buf, bench.BATCH, 200)
