@@ -7,7 +7,10 @@
 set -e
 TAG=${1:-r02}
 OUT=$PWD/gpurun_out/prof_$TAG
-ARGS="--no-cpu-baseline --no-relabel --agents-per-gpu 0 --ensemble-q 0 --min-timed-s 0.05"
+# (--unroll 50: the traced runs replay hipGraphs of 50 steps.  bench.py's default, plain kernel launches,
+# is paced by the tracer's per-dispatch interception -- ~6 us per launch, 18.7 us per step instead of
+# 14.9 -- and the "durations" of kernels that tile the step then measure the tool, not the kernels.)
+ARGS="--unroll 50 --no-cpu-baseline --no-relabel --agents-per-gpu 0 --ensemble-q 0 --min-timed-s 0.05"
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 3000 --warmup 300 $ARGS > $OUT/trace.json
