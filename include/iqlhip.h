@@ -217,7 +217,9 @@ int iqlhip_trainer_set_lr(iqlhip_trainer *t, double lr_q, double lr_v, double lr
  *   [n_steps][2][batch][hidden] (1 = keep); ignored without actor dropout.
  * losses_out: NULL or device fp32[n_steps][3] = value_loss, q_loss, actor_loss
  *   of each step (ref:589,607,633).
- * graph_unroll: > 0 replays a captured hipGraph of that many steps per launch.
+ * graph_unroll: > 0 replays a captured hipGraph of that many steps per launch;
+ *   0: plain kernel launches, three per step, from this call's loop (one seed: the
+ *   faster mode, a graph launch costs ~5 us of device time; seed groups: graphs of 50).
  * Asynchronous on `stream`, except that a call never leaves more than
  * IQLHIP_MAX_INFLIGHT kernel dispatches (environment, default 6144, 0 = no bound;
  * 3 per step) queued: beyond that it waits for the oldest third of them.      */
