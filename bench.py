@@ -186,6 +186,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
+    # stdout carries the ONE JSON line and nothing else: whatever the package prints on the way (the
+    # reference-style "Dataset size" / "Training IQL" banners of the dataset loader and of train()) goes
+    # to stderr
+    json_out = sys.stdout
+    sys.stdout = sys.stderr
+
     import torch
     import torch.distributed as dist
 
@@ -404,7 +410,7 @@ def main():
                 out["relabel"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
