@@ -55,9 +55,9 @@ for G, K in combos:
             for g, s in zip(groups, streams):
                 with torch.cuda.stream(s):
                     if K > 1:
-                        g.train_steps(buf, chunk, bench.BATCH, graph_unroll=50)
+                        g.train_steps(buf, chunk, bench.BATCH, graph_unroll=int(os.environ.get('GS_UNROLL', '50')))
                     else:
-                        g.train_steps(buf, chunk, bench.BATCH, return_losses=False, graph_unroll=50)
+                        g.train_steps(buf, chunk, bench.BATCH, return_losses=False, graph_unroll=int(os.environ.get('GS_UNROLL', '50')))
     run(1000)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
