@@ -27,6 +27,7 @@ int update_lds_floats();
 hipError_t launch_update(bool, const TrainerDesc *, const DevArgs *, DevCtr *, const UpdItem *, int,
                          int n_seeds, hipStream_t);
 hipError_t launch_sync_weights(bool, const TrainerDesc *, hipStream_t);
+hipError_t prepare_step_kernels();
 
 hipError_t launch_infer(bool, const TrainerDesc &, const TrainerDesc *, const FwdNet &, const float *,
                         const float *, int64_t, float *, int, hipStream_t);
@@ -396,6 +397,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   if (int e = check_cfg(cfg)) return e;
   if (!ar || !ar->params || !ar->exp_avg || !ar->exp_avg_sq || !ar->target)
     return fail(IQLHIP_ERR_INVALID, "null arena pointer");
+  HIP_TRY(prepare_step_kernels());
   iqlhip_trainer *t = new (std::nothrow) iqlhip_trainer();
   if (!t) return fail(IQLHIP_ERR_NOMEM, "host allocation failed");
   t->cfg = *cfg;

@@ -783,6 +783,283 @@ __global__ __launch_bounds__(256, PRE ? 1 : (MT >= 4 ? 2 : 3)) void k_forward(co
 }
 
 // ========================================================================
+// k_forward_tp: the forward pass of launches with MANY rows (seed groups, batch-1024 critic
+// ensembles; bf16, H = 256).  Same arithmetic as k_forward, element for element -- every
+// accumulator sums its k-steps in ascending order from zero, the output layer leaves the same
+// partial plane per 64-unit part of hidden layer 2 -- so a seed stepped by this kernel is
+// bit-identical to the seed stepped by k_forward.  What differs is the shape of a work-group.
+//
+// k_forward is cut for ONE seed at batch 256: 16 or 32 rows x one or two 64-unit parts per
+// work-group, 450+ short chains on an idle chip.  With 11,000-14,000 row-evaluations per launch
+// the stamps (round 4, tools/stamps.py STAMP_E=4 STAMP_B=1024) show those work-groups waiting on
+// each other's weight fragments: a 32-row x 128-unit work-group pulls 112 KB of fragments through
+// its CU's vector-memory path (~46 B/clk: a 1 KiB fragment per ~22 cycles, MI355X_MICROARCH
+// "vmcnt drain"), three of them share a CU, layer 1 is recomputed per part group, and 12 jobs on
+// 8 XCDs run as two rounds.  Here a work-group is 64 rows x ALL of a network (8 waves, two n-tiles
+// of every layer each): 168 KB of fragments per 64 rows instead of 224, layer 1 once per slab, every
+// fragment requested before the first dependent instruction, one work-group per CU (176 of them
+// for 4 critics at batch 1024, 224 for 8 seeds at batch 256: the whole launch is resident at once).
+// ========================================================================
+template <int H>
+__global__ __launch_bounds__(512, 1) void k_forward_tp(const TrainerDesc *__restrict__ Dp,
+                                                        const DevArgs *__restrict__ Ap,
+                                                        const DevCtr *__restrict__ Cp, const int nsl_,
+                                                        const int nfwd_) {
+  using C = FCfg<true, H>;
+  using P = Prec<true>;
+  using T = typename P::T;
+  constexpr int ROWS = 64, MT = ROWS / 16, NW = 8;
+  constexpr int TPW = H / (16 * NW);  // n-tiles per wave, layers 1 and 2
+  constexpr int SPL = C::SPL, HP = C::HP, NK2 = C::NK2, NK3 = C::NK3;
+  static_assert(H == 256 && TPW == 2 && SPL == 4, "k_forward_tp is built for H = 256");
+  Dp += blockIdx.y, Ap += blockIdx.y, Cp += blockIdx.y;
+  const TrainerDesc &D = *Dp;
+  // job j (evaluation j < nfwd, or the spare job nfwd) lives on XCD j & 7, round j >> 3
+  const int idx_ = blockIdx.x >> 3;
+  const int fnet = (idx_ / nsl_) * 8 + (blockIdx.x & 7);
+  const int slab = idx_ % nsl_;
+  if (fnet > nfwd_) return;
+  if (fnet == nfwd_) {
+    if (slab == 0 && threadIdx.x == 0) {
+      write_adam_coef(D, *Ap, Cp->ctr[0] + 1, const_cast<AdamCoef *>(&Cp->coef));
+      const_cast<DevCtr *>(Cp)->coef_step = Cp->ctr[0] + 1;
+    }
+    if (slab == 0 && !D.deterministic && (int)threadIdx.x < D.A)
+      stg(D.ls_snap + threadIdx.x, ldg(D.params + D.off_log_std + threadIdx.x));
+    return;
+  }
+  // ---- ONE batch of scalar loads ----
+  const FwdNet N = D.fwd[fnet];
+  const int B = D.B, BP = D.BP, OUTW = D.OUTW, k1max = D.k1max;
+  const float *const stage = D.stage_rows;
+  const unsigned sstride = (unsigned)D.stage_stride;
+  float *const g_outs = D.outs;
+  void *const g_hT = D.hT;
+  const int64_t step = Cp->ctr[0];  // dropout masks only
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int K1P = k1max + P::EPV;
+  T *xs = reinterpret_cast<T *>(smem);  // [ROWS][K1P]
+  T *h1 = xs + ROWS * K1P;              // [ROWS][HP]
+  T *h2 = h1 + ROWS * HP;               // [ROWS][HP]
+  STAMP(0, 0);
+
+  // ---- the input rows first: 8 lanes per row, four 16-byte loads each (columns 4 l8 + 32 j) ----
+  const int rr = tid >> 3, l8 = tid & 7;
+  const int lim4 = round_up(N.in_dim, 4) - 4;
+  float4 xq[4];
+  {
+    const int row_ = slab * ROWS + rr;
+    const unsigned row = (unsigned)(row_ < B ? row_ : B - 1);
+    const float *src = stage + N.in_off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 4 * l8 + 32 * j;
+      xq[j] = __builtin_bit_cast(float4, ldg16(src + (row * sstride + (unsigned)(c < lim4 ? c : lim4))));
+    }
+  }
+  // ---- every weight fragment this wave will need, in the order of use ----
+  const int nk1 = N.k1pad / P::KM;
+  const int nt3 = N.out_pad / 16;
+  const int tile0 = wave * TPW;       // this wave's first n-tile of layers 1 and 2
+  const int part = tile0 / 4;         // the 64-unit part of layer 2 its tiles belong to (layer-3 K-slice)
+  float bias1[TPW], bias2[TPW], bias3[2];
+#pragma unroll
+  for (int jj = 0; jj < TPW; ++jj) {
+    bias1[jj] = ldg(N.b1 + 16 * (tile0 + jj) + r);
+    bias2[jj] = ldg(N.b2 + 16 * (tile0 + jj) + r);
+  }
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+    bias3[jt] = ldg(N.b3 + (16 * jt + r < N.out_dim ? 16 * jt + r : N.out_dim - 1));
+  uint4 w1[C::NK1][TPW], w2[TPW][NK2], w3[NK3][2];
+  {
+    const T *W1w = reinterpret_cast<const T *>(N.w1c) + (size_t)tile0 * nk1 * 64 * P::EPV;
+#pragma unroll
+    for (int ks = 0; ks < C::NK1; ++ks) {
+      if (ks < nk1) {
+#pragma unroll
+        for (int jj = 0; jj < TPW; ++jj)
+          w1[ks][jj] = ldg16(W1w + (size_t)(jj * nk1 + ks) * 64 * P::EPV + lane * P::EPV);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < TPW; ++jj) {
+      const T *W2w = reinterpret_cast<const T *>(N.w2c) + (size_t)(tile0 + jj) * NK2 * 64 * P::EPV;
+#pragma unroll
+      for (int ks = 0; ks < NK2; ++ks) w2[jj][ks] = ldg16(W2w + ks * 64 * P::EPV + lane * P::EPV);
+    }
+    const T *W3w = reinterpret_cast<const T *>(N.w3c) + (size_t)(part * NK3) * 64 * P::EPV;
+#pragma unroll
+    for (int ks = 0; ks < NK3; ++ks)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+        if (jt < nt3) w3[ks][jt] = ldg16(W3w + (size_t)(jt * NK2 + ks) * 64 * P::EPV + lane * P::EPV);
+  }
+  STAMP(0, 1);
+
+  // ---- layer-1 input into LDS ----
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = 4 * l8 + 32 * j;
+    const float v[4] = {xq[j].x, xq[j].y, xq[j].z, xq[j].w};
+    if (c < N.k1pad) {
+      T tv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tv[e] = P::from_f32(c + e < N.in_dim ? v[e] : 0.f);
+      uint2 u;
+      u.x = (uint32_t)tv[0] | ((uint32_t)tv[1] << 16), u.y = (uint32_t)tv[2] | ((uint32_t)tv[3] << 16);
+      *reinterpret_cast<uint2 *>(xs + rr * K1P + c) = u;
+    }
+  }
+  __syncthreads();
+  STAMP(0, 2);
+
+  const bool lean = !N.dropout;  // (wave-uniform) see relu_bias_bf16x4
+  // ---- hidden layer 1 ----
+  {
+    f32x4 acc[MT][TPW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int jj = 0; jj < TPW; ++jj) acc[m][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < C::NK1; ++ks) {
+      if (ks < nk1) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const uint4 a = *reinterpret_cast<const uint4 *>(xs + (16 * m + r) * K1P + ks * P::KM + P::EPV * q);
+#pragma unroll
+          for (int jj = 0; jj < TPW; ++jj) P::mma(a, w1[ks][jj], acc[m][jj]);
+        }
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < TPW; ++jj) {
+      const int col = 16 * (tile0 + jj) + r;
+      const float bias = P::round(bias1[jj]);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int row0 = slab * ROWS + 16 * m;
+        if (lean) {
+          const uint2 u = relu_bias_bf16x4(acc[m][jj], bias);
+          T *hrow = h1 + (16 * m + 4 * q) * HP + col;
+          hrow[0] = (T)(u.x & 0xffff), hrow[HP] = (T)(u.x >> 16);
+          hrow[2 * HP] = (T)(u.y & 0xffff), hrow[3 * HP] = (T)(u.y >> 16);
+          if (N.train_slot >= 0 && row0 < B)
+            act_store8(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 0) * H * BP,
+                       fidx<P>(col, row0 + 4 * q, BP / P::KM), u);
+          continue;
+        }
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(P::round(acc[m][jj][i] + bias), 0.f);
+        if (N.dropout) {
+          bool keep[4];
+          dropout_keep4(D, *Ap, step, 0, (row0 >> 2) + q, col, keep);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = keep[i] ? P::round(v[i] * D.drop_scale) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h1[(16 * m + 4 * q + i) * HP + col] = P::from_f32(v[i]);
+        if (N.train_slot >= 0 && row0 < B)
+          store4T<true>(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 0) * H * BP +
+                            fidx<P>(col, row0 + 4 * q, BP / P::KM), v);
+      }
+    }
+  }
+  __syncthreads();
+  STAMP(0, 3);
+
+  // ---- hidden layer 2 ----
+  {
+    f32x4 acc[TPW][MT];
+#pragma unroll
+    for (int jj = 0; jj < TPW; ++jj)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[jj][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NK2; ++ks) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(h1 + (16 * m + r) * HP + ks * P::KM + P::EPV * q);
+#pragma unroll
+        for (int jj = 0; jj < TPW; ++jj) P::mma(a, w2[jj][ks], acc[jj][m]);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < TPW; ++jj) {
+      const int col = 16 * (tile0 + jj) + r;
+      const float bias = P::round(bias2[jj]);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int row0 = slab * ROWS + 16 * m;
+        if (lean) {
+          const uint2 u = relu_bias_bf16x4(acc[jj][m], bias);
+          T *hrow = h2 + (16 * m + 4 * q) * HP + col;
+          hrow[0] = (T)(u.x & 0xffff), hrow[HP] = (T)(u.x >> 16);
+          hrow[2 * HP] = (T)(u.y & 0xffff), hrow[3 * HP] = (T)(u.y >> 16);
+          if (N.train_slot >= 0 && row0 < B)
+            act_store8(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP,
+                       fidx<P>(col, row0 + 4 * q, BP / P::KM), u);
+          continue;
+        }
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(P::round(acc[jj][m][i] + bias), 0.f);
+        if (N.dropout) {
+          bool keep[4];
+          dropout_keep4(D, *Ap, step, 1, (row0 >> 2) + q, col, keep);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = keep[i] ? P::round(v[i] * D.drop_scale) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h2[(16 * m + 4 * q + i) * HP + col] = P::from_f32(v[i]);
+        if (N.train_slot >= 0 && row0 < B)
+          store4T<true>(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP +
+                            fidx<P>(col, row0 + 4 * q, BP / P::KM), v);
+      }
+    }
+  }
+  __syncthreads();
+  STAMP(0, 4);
+
+  // ---- output layer: one partial plane per 64-unit part, as k_forward leaves them (no rounding:
+  // the consumer adds the parts in fp32, then rounds once).  The (part, row tile) pairs are dealt
+  // over the waves: wave w holds the layer-3 K-slice of part w / 2 and takes two of its row tiles.
+  {
+    float *outp = g_outs + (size_t)part * B * OUTW;
+#pragma unroll
+    for (int mm = 0; mm < MT / 2; ++mm) {
+      const int m = (wave & 1) * (MT / 2) + mm;
+      f32x4 acc3[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < NK3; ++ks) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(h2 + (16 * m + r) * HP + 64 * part + ks * P::KM + P::EPV * q);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+          if (jt < nt3) P::mma(a, w3[ks][jt], acc3[jt]);
+      }
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        const int col = 16 * jt + r;
+        if (jt < nt3 && col < N.out_dim) {
+          const float bias = part == 0 ? P::round(bias3[jt]) : 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = slab * ROWS + 16 * m + 4 * q + i;
+            if (row < B) stg(outp + (size_t)row * OUTW + N.out_col + col, acc3[jt][i] + bias);
+          }
+        }
+      }
+    }
+  }
+  STAMP(0, 5);
+}
+
+// ========================================================================
 // k_infer: forward pass of one network on dense inputs (iqlhip_forward;
 // ref:452-543 forward()).  Rows beyond n are computed on zeros and not stored.
 // ========================================================================
@@ -1173,6 +1450,277 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
 }
 
 // ========================================================================
+// k_backward_tp: the backward pass of launches with many rows (bf16, H = 256; see k_forward_tp).
+// One work-group = (trained net, 32 batch rows, ALL dZ1 columns): 512 threads, the two halves of
+// the work-group run the loss / dZ3 / dZ2 phases of k_backward for one 16-row slab each (the
+// same thread -> element map, the same order of every sum), then all eight waves share the
+// closing GEMM dZ1 = dZ2 W2 -- two n-tiles x both slabs per wave.  k_backward cuts the dZ1
+// columns into parts so that ONE seed fills the chip: every part group repeats the loss / dZ2
+// phase and streams its share of W2^T per 16 rows (64 KB per work-group, 768 work-groups for four
+// critics at batch 1024).  Here nothing is repeated and W2^T is streamed once per 32 rows
+// (192-256 work-groups, one per CU, every operand requested up front).  The same bits as k_backward.
+// ========================================================================
+template <int H>
+__global__ __launch_bounds__(512, 1) void k_backward_tp(const TrainerDesc *__restrict__ Dp,
+                                                         const DevArgs *__restrict__ Ap, DevCtr *__restrict__ Cp,
+                                                         const int nslab32, const int ntrain, const int nxn) {
+  constexpr bool BF16 = true;
+  using K = KCfg<true, H>;
+  using C = FCfg<true, H>;
+  using P = Prec<true>;
+  using T = typename P::T;
+  constexpr int SPL = C::SPL, NW = 8, TPW = H / (16 * NW), HP = K::HP;
+  static_assert(H == 256 && TPW == 2, "k_backward_tp is built for H = 256");
+  Dp += blockIdx.y, Cp += blockIdx.y;
+  const TrainerDesc &D = *Dp;
+  // Virtual job vj = nxn net + (slab32 % nxn) lives on XCD vj & 7, round vj >> 3: with few trained
+  // nets (TwinQ: 4) each takes nxn = 2 XCDs, so that a group launch uses all eight.
+  const int blk = (int)blockIdx.x;
+  const int idx_ = blk >> 3;
+  const int per_vj = nslab32 / nxn;
+  const int vj = (idx_ / per_vj) * 8 + (blk & 7), s_in = idx_ % per_vj;
+  const int net = vj / nxn, slab32 = s_in * nxn + vj % nxn;
+  if (net >= ntrain) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // ---- ONE batch of scalar loads ----
+  const int out_dim = D.net[net].out_dim, out_pad = D.net[net].out_pad;
+  const void *const p_w2ct = D.net[net].w2ct, *const p_w3t = D.net[net].w3t;
+  const int B = D.B, BP = D.BP, OUTW = D.OUTW, n_act = D.A, opmax = D.opmax;
+  const float *const g_outs = D.outs, *const g_rd = D.rd, *const g_actf = D.actf;
+  const float *const g_ls = D.deterministic ? D.actf : D.ls_snap;
+  const T *const g_hT = reinterpret_cast<const T *>(D.hT);
+  T *const g_dz1T = reinterpret_cast<T *>(D.dz1T), *const g_dz2T = reinterpret_cast<T *>(D.dz2T);
+  T *const g_dz3T = reinterpret_cast<T *>(D.dz3T);
+  float *const g_lsp = D.lsp, *const g_lossp = D.lossp;
+  const bool drop_on = D.has_dropout && net == D.net_a;
+  const float drop_scale = D.drop_scale;
+  const bool is_gauss_actor = net == D.net_a && !D.deterministic;
+  const int out_qt = D.out_qt, out_v = D.out_v, out_nv = D.out_nv, out_mean = D.out_mean, n_crit = D.E;
+  const int tid_ = threadIdx.x, lane = tid_ & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+  const int sub = wave >> 2;         // which 16-row slab of the pair this half of the work-group owns
+  const int tid = tid_ & 255;        // thread index inside the half: k_backward's tid
+  const int slab = slab32 * 2 + sub; // 16-row slab index, as in k_backward
+  const int nslab = B / SLAB;
+  const int r = lane & 15, q = lane >> 4;
+  const int nkb = BP / P::KM;
+  const float fB = (float)B;
+
+  constexpr int SUB_BYTES = SLAB * HP * 2 + 3 * SLAB * 32 * 4 + SLAB * 4 + SLAB * FIN_LD * 4;
+  static_assert(SUB_BYTES % 16 == 0, "LDS regions stay 16-byte aligned");
+  char *const sm = smem + sub * SUB_BYTES;
+  T *dz2s = reinterpret_cast<T *>(sm);                         // [16][HP]
+  float *dz3 = reinterpret_cast<float *>(dz2s + SLAB * HP);    // [32][16]
+  float *lterm = dz3 + SLAB * 32;
+  float *gstd = lterm + SLAB * 32;
+  float *rowsum = gstd + SLAB * 32;                            // [16]
+  float *fin = rowsum + SLAB;                                  // [16][FIN_LD]
+
+  if (blk == 0 && tid_ == 0) Cp->ctr[1] = Cp->ctr[0] + 1;
+  STAMP(1, 0);
+
+  // ---- the loss inputs first (thread (row tid / 16, lane16 = tid % 16) of its half) ----
+  const int lrow = tid >> 4, lj = tid & 15;
+  const int brow = slab * SLAB + lrow;
+  float pv[FIN_NC][SPL];
+  {
+    const float *o = g_outs + (size_t)brow * OUTW;
+#pragma unroll
+    for (int c = 0; c < FIN_NC; ++c) {
+      const int col = lj + 16 * c;
+      const unsigned cc = (unsigned)(col < OUTW ? col : OUTW - 1);
+#pragma unroll
+      for (int p = 0; p < SPL; ++p) pv[c][p] = ldg(o + ((unsigned)p * (unsigned)(B * OUTW) + cc));
+    }
+  }
+  const float rew = ldg(g_rd + (size_t)brow * 2), done = ldg(g_rd + (size_t)brow * 2 + 1);
+  float actv[2], lsv[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int jc = lj + 16 * h < n_act ? lj + 16 * h : n_act - 1;
+    actv[h] = ldg(g_actf + (size_t)brow * n_act + jc);
+    lsv[h] = ldg(g_ls + jc);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const int c2 = tid;  // hidden unit this thread owns in the dZ2 phase (H = 256 = threads per half)
+  constexpr int W3G = 32 / P::EPV;
+  uint4 w3q[W3G];
+  {
+    const T *w3row = reinterpret_cast<const T *>(p_w3t) + (size_t)c2 * out_pad;
+#pragma unroll
+    for (int g = 0; g < W3G; ++g)
+      if (g * P::EPV < out_pad) w3q[g] = ldg16(w3row + g * P::EPV);
+  }
+  float h2v[16];
+  {
+    const T *h2T = g_hT + (size_t)(net * 2 + 1) * H * BP;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      load4T<BF16>(h2T + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), &h2v[4 * g4]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // the operands of the closing GEMM: wave w -> n-tiles 2w, 2w + 1 of dZ1, both slabs of the pair
+  const int tile0 = wave * TPW;
+  uint4 w2t[TPW][K::NK2];
+  float h1v[TPW][2][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const T *W2Tw = reinterpret_cast<const T *>(p_w2ct) + (size_t)(tile0 + t) * K::NK2 * 64 * P::EPV;
+#pragma unroll
+    for (int ks = 0; ks < K::NK2; ++ks) w2t[t][ks] = ldg16(W2Tw + ks * 64 * P::EPV + lane * P::EPV);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+      load4T<BF16>(g_hT + (size_t)(net * 2 + 0) * H * BP +
+                       fidx<P>(16 * (tile0 + t) + r, (slab32 * 2 + m) * SLAB + 4 * q, nkb), h1v[t][m]);
+  }
+  STAMP(1, 1);
+
+  // ---- finish the forward outputs of this slab (sum of the parts, rounding, tanh) ----
+#pragma unroll
+  for (int c = 0; c < FIN_NC; ++c) {
+    const int col = lj + 16 * c;
+    if (col < OUTW) {
+      float sum = pv[c][0];
+#pragma unroll
+      for (int p = 1; p < SPL; ++p) sum += pv[c][p];
+      const float v = P::round(sum);
+      fin[lrow * FIN_LD + col] = (col >= out_mean && col < out_mean + n_act) ? P::round(tanhf(v)) : v;
+    }
+  }
+  __syncthreads();
+
+  // ---- per-row loss terms and d(loss)/d(out)  (ref:581-637) ----
+  {
+    const float *f = fin + lrow * FIN_LD;
+    LossIn lin;
+#pragma unroll
+    for (int e = 0; e < MAX_CRITICS; ++e) lin.qt[e] = f[out_qt + (e < n_crit ? e : 0)];
+    lin.vv = f[out_v], lin.nv = f[out_nv], lin.qv = f[net < n_crit ? net : 0];
+    lin.rew = rew, lin.done = done;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = lj + 16 * h;
+      if (h == 0 || out_dim > 16) {
+        lin.mean = f[out_mean + (j < n_act ? j : n_act - 1)];
+        lin.act = actv[h], lin.ls = lsv[h];
+        float d3, lt, gs;
+        loss_terms<BF16>(D, net, lin, fB, d3, lt, gs);
+        if (j < out_dim) dz3[j * SLAB + lrow] = d3, lterm[j * SLAB + lrow] = lt, gstd[j * SLAB + lrow] = gs;
+      }
+    }
+  }
+  __syncthreads();
+  STAMP(1, 2);
+
+  if (tid < SLAB) {
+    float s = 0.f;
+    for (int j = 0; j < out_dim; ++j) s += lterm[j * SLAB + tid];
+    rowsum[tid] = s;
+  }
+  if (is_gauss_actor && tid >= 64 && tid < 64 + n_act) {
+    const int j = tid - 64;
+    float s = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < SLAB; ++rr) s += gstd[j * SLAB + rr];
+    stg(g_lsp + (size_t)slab * n_act + j, s);
+  }
+  for (int e = tid; e < out_dim * SLAB; e += 256) {
+    const int j = e / SLAB, rr = e - j * SLAB;
+    stg(g_dz3T + (size_t)net * opmax * BP + fidx<P>(j, slab * SLAB + rr, nkb), P::from_f32(dz3[j * SLAB + rr]));
+  }
+
+  // ---- dZ2 = (dZ3 W3) * relu'(h2)   (VALU: K = out_dim <= 32) ----
+  {
+    T *dst = g_dz2T + (size_t)net * H * BP;
+    float s[SLAB];
+#pragma unroll
+    for (int rr = 0; rr < SLAB; ++rr) s[rr] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      if (j < out_dim) {
+        const uint4 &g = w3q[j / P::EPV];
+        const uint32_t wds[4] = {g.x, g.y, g.z, g.w};
+        const uint32_t wd = wds[(j % 8) >> 1];
+        const float w3j = bf2f((uint16_t)((j & 1) ? (wd >> 16) : (wd & 0xffff)));
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float4 dv = *reinterpret_cast<const float4 *>(&dz3[j * SLAB + 4 * g4]);
+          s[4 * g4] += dv.x * w3j, s[4 * g4 + 1] += dv.y * w3j;
+          s[4 * g4 + 2] += dv.z * w3j, s[4 * g4 + 3] += dv.w * w3j;
+        }
+      }
+    }
+    const bool lean = !drop_on;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      if (lean) {
+        float t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = h2v[4 * g4 + i] > 0.f ? s[4 * g4 + i] : 0.f;
+        const uint2 u = make_uint2(pk_bf16(t[0], t[1]), pk_bf16(t[2], t[3]));
+        T *drow = dz2s + (4 * g4) * HP + c2;
+        drow[0] = (T)(u.x & 0xffff), drow[HP] = (T)(u.x >> 16);
+        drow[2 * HP] = (T)(u.y & 0xffff), drow[3 * HP] = (T)(u.y >> 16);
+        act_store8(dst, fidx<P>(c2, slab * SLAB + 4 * g4, nkb), u);
+        continue;
+      }
+      float outv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rr = 4 * g4 + i;
+        float sv = P::round(s[rr]);
+        if (drop_on) sv = P::round(sv * drop_scale);
+        outv[i] = h2v[rr] > 0.f ? sv : 0.f;
+        dz2s[rr * HP + c2] = P::from_f32(outv[i]);
+      }
+      store4T<BF16>(dst + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), outv);
+    }
+  }
+  __syncthreads();
+  STAMP(1, 3);
+  if (tid == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < SLAB; ++rr) s += rowsum[rr];
+    stg(g_lossp + net * nslab + slab, s);
+  }
+
+  // ---- dZ1 = (dZ2 W2) * relu'(h1)   (MFMA; wave w: n-tiles 2w, 2w + 1 x both slabs) ----
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const T *xrow = reinterpret_cast<const T *>(smem + m * SUB_BYTES) + r * HP + P::EPV * q;
+#pragma unroll
+      for (int ks = 0; ks < K::NK2; ++ks) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(xrow + ks * P::KM);
+        P::mma(a, w2t[t][ks], acc);
+      }
+      const int col = 16 * (tile0 + t) + r;
+      const int row0 = (slab32 * 2 + m) * SLAB;
+      if (!drop_on) {
+        float tv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tv[i] = h1v[t][m][i] > 0.f ? acc[i] : 0.f;
+        act_store8(g_dz1T + (size_t)net * H * BP, fidx<P>(col, row0 + 4 * q, nkb),
+                   make_uint2(pk_bf16(tv[0], tv[1]), pk_bf16(tv[2], tv[3])));
+      } else {
+        float outv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float sv = P::round(acc[i]);
+          sv = P::round(sv * drop_scale);
+          outv[i] = h1v[t][m][i] > 0.f ? sv : 0.f;
+        }
+        store4T<BF16>(g_dz1T + (size_t)net * H * BP + fidx<P>(col, row0 + 4 * q, nkb), outv);
+      }
+    }
+  }
+  STAMP(1, 4);
+}
+
+// ========================================================================
 // k_update
 // ========================================================================
 // Polyak update of a target weight t towards the new weight p.  Two forms, different rounding:
@@ -1191,26 +1739,29 @@ __device__ __forceinline__ float polyak(const TrainerDesc &D, float t, float p) 
 }
 
 // A/B on one box (round 3, r4m): one seed 64.1k -> 65.6k steps/s, 8 seeds per launch 175.0k -> 177.4k;
-// every parity test unchanged at its tolerance.  -DIQL_ADAM_FAST=0 builds the IEEE form.
+// every parity test unchanged at its tolerance.  -DIQL_ADAM_FAST=0 builds the IEEE form everywhere.
+// FAST is the bf16 step's form only: precision = fp32 (the parity mode) keeps torch's arithmetic --
+// _single_tensor_adam's correctly rounded sqrt and two divisions, operation for operation.
 #ifndef IQL_ADAM_FAST
 #define IQL_ADAM_FAST 1
 #endif
+template <bool FAST>
 __device__ __forceinline__ void adam_apply(float &p, float &m, float &v, float g, const AdamCoef &c,
                                            float neg_step) {
 #pragma clang fp contract(off)
   m = __builtin_fmaf(g - m, c.one_m_b1, m);                 // exp_avg.lerp_(grad, 1 - beta1)
   v = __builtin_fmaf(c.b2, v, (c.one_m_b2 * g) * g);        // mul_(beta2).addcmul_(g, g, 1 - beta2)
-#if IQL_ADAM_FAST
-  // denom = sqrt(v) / sqrt(bc2) + eps and m / denom on the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32
-  // and a precomputed reciprocal instead of two correctly rounded divisions and a correctly rounded
-  // square root (~10 vector instructions each, three quarters of the Adam pass): the step differs
-  // from the IEEE form by <= ~3e-7 of itself, i.e. <= 1e-10 absolute at lr = 3e-4
-  const float denom = __builtin_fmaf(__builtin_amdgcn_sqrtf(v), c.inv_bc2_sqrt, c.eps);
-  p = __builtin_fmaf(neg_step, m * __builtin_amdgcn_rcpf(denom), p);
-#else
-  const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
-  p = __builtin_fmaf(neg_step, m / denom, p);               // addcdiv_(exp_avg, denom, -step_size)
-#endif
+  if constexpr (FAST) {
+    // denom = sqrt(v) / sqrt(bc2) + eps and m / denom on the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32
+    // and a precomputed reciprocal instead of two correctly rounded divisions and a correctly rounded
+    // square root (~10 vector instructions each, three quarters of the Adam pass): the step differs
+    // from the IEEE form by <= ~3e-7 of itself, i.e. <= 1e-10 absolute at lr = 3e-4
+    const float denom = __builtin_fmaf(__builtin_amdgcn_sqrtf(v), c.inv_bc2_sqrt, c.eps);
+    p = __builtin_fmaf(neg_step, m * __builtin_amdgcn_rcpf(denom), p);
+  } else {
+    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+    p = __builtin_fmaf(neg_step, m / denom, p);             // addcdiv_(exp_avg, denom, -step_size)
+  }
 }
 
 // beta^t by binary exponentiation (t <= 2^31): a few ulp, ~60 double multiplies
@@ -1366,6 +1917,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
                                             const int blk) {
   using P = Prec<BF16>;
   using T = typename P::T;
+  constexpr bool AF = BF16 && IQL_ADAM_FAST != 0;  // (see adam_apply)
   constexpr int UWAVES = UT / 64;
   constexpr int URPP = UT / UTPR;                  // tile rows per pass
   constexpr int UNP = UTO / URPP;                  // passes
@@ -1415,7 +1967,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       const float lsc = fminf(fmaxf(ls, -20.f), 2.f);
       g = g * expf(lsc) * ((ls >= -20.f && ls <= 2.f) ? 1.f : 0.f);
       float p = ls;
-      adam_apply(p, pm, pv, g, coef, coef.neg_step[2]);
+      adam_apply<AF>(p, pm, pv, g, coef, coef.neg_step[2]);
       stg(D.params + o, p), stg(D.exp_avg + o, pm), stg(D.exp_avg_sq + o, pv);
       if (D.grads) stg(D.grads + o, g);
     }
@@ -1600,7 +2152,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
         const int ol = e / Idim, i = e - ol * Idim;
         const float g = P::round(tile[ol * TLD + i]);
         float p_ = pf[k], m_ = mf[k], v_ = vf[k];
-        adam_apply(p_, m_, v_, g, coef, neg_step);
+        adam_apply<AF>(p_, m_, v_, g, coef, neg_step);
         tile[ol * TLD + i] = p_;
         state_store1(g_params, fbase + e, p_), state_store1(g_m, fbase + e, m_), state_store1(g_v, fbase + e, v_);
         if (g_grads) stg(g_grads + fbase + e, g);
@@ -1614,7 +2166,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     if (tid < USR) {
       const int64_t e = it.off_b + o0 + tid;
       const float g = P::round(bgrad[tid]);
-      adam_apply(pb, mb, vb, g, coef, neg_step);
+      adam_apply<AF>(pb, mb, vb, g, coef, neg_step);
       stg(g_params + e, pb), stg(g_m + e, mb), stg(g_v + e, vb);
       if (g_grads) stg(g_grads + e, g);
       if (has_target) stg(g_target + it.toff_b + o0 + tid, polyak(D, tb, pb));
@@ -1873,7 +2425,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       g[k] = P::round(g[k]);
-      adam_apply(p[k], m[k], v[k], g[k], coef, neg_step);
+      adam_apply<AF>(p[k], m[k], v[k], g[k], coef, neg_step);
       if (has_target) tv[k] = polyak(D, tv[k], p[k]);
     }
     // the new weights replace this thread's gradients in the tile (step 4 reads them transposed)
@@ -1908,7 +2460,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   if (do_bias && tid < UTO && o0 + tid < Odim) {
     const int64_t e = it.off_b + o0 + tid;
     const float g = P::round(bgrad[tid]);
-    adam_apply(pb, mb, vb, g, coef, neg_step);
+    adam_apply<AF>(pb, mb, vb, g, coef, neg_step);
     stg(g_params + e, pb), stg(g_m + e, mb), stg(g_v + e, vb);
     if (g_grads) stg(g_grads + e, g);
     if (has_target) stg(g_target + it.toff_b + o0 + tid, polyak(D, tb, pb));
@@ -2068,8 +2620,33 @@ int fwd_parts_per_wg(int B, int H, int n_seeds) {
     }                                            \
   } while (0)
 
+// Launches with many rows (seed groups, batch-1024 ensembles) take the throughput kernels
+// k_forward_tp / k_backward_tp (bf16, H = 256, batch a multiple of 64); IQLHIP_TP=0 / 1 forces the choice.
+bool use_tp(bool bf16, const TrainerDesc &D, int n_seeds) {
+  static const int forced = getenv("IQLHIP_TP") ? atoi(getenv("IQLHIP_TP")) : -1;  // A/B knob
+  if (!bf16 || D.H != 256 || D.B % 64 != 0) return false;
+  if (forced >= 0) return forced != 0;
+  return false;  // (round 4, first measurement: NOT faster than k_forward / k_backward -- opt-in until it is)
+}
+// once per trainer (iqlhip_trainer_create, outside any stream capture): k_forward_tp's 64-row slabs
+// take more than the 64 KB of dynamic LDS a kernel may use by default
+hipError_t prepare_step_kernels() {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(k_forward_tp<256>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+size_t fwd_tp_smem_bytes(int H, int k1max) { return (size_t)64 * ((k1max + 8) + 2 * (H + 8)) * 2; }
+size_t bwd_smem_bytes(bool bf16, int H);
+
 hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
                           const DevCtr *c, int n_seeds, hipStream_t st) {
+  if (use_tp(bf16, D, n_seeds)) {
+    const int nsl64 = D.B / 64;
+    const int grid = 8 * ((D.nfwd + 1 + 7) / 8) * nsl64;
+    // (more than 64 KB of dynamic LDS: allowed by prepare_step_kernels, at trainer creation)
+    hipLaunchKernelGGL((k_forward_tp<256>), dim3(grid, n_seeds), dim3(512), fwd_tp_smem_bytes(256, D.k1max), st, dD, a,
+                       c, nsl64, D.nfwd);
+    return hipGetLastError();
+  }
   const int mt = fwd_row_tiles(D.B, n_seeds), nsl = (D.B + 16 * mt - 1) / (16 * mt);
   const int pw = fwd_parts_per_wg(D.B, D.H, n_seeds);
   // nfwd evaluations + the spare job, each nsl slabs x (SPL / pw) part groups
@@ -2109,6 +2686,14 @@ int bwd_parts_per_wg(int B, int H, int n_seeds) {
 }
 hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
                            DevCtr *c, int n_seeds, hipStream_t st) {
+  if (use_tp(bf16, D, n_seeds)) {
+    const int nslab32 = D.B / 32;
+    const int nxn = (D.ntrain <= 4 && nslab32 % 2 == 0) ? 2 : 1;  // XCDs per trained net
+    const int grid = 8 * ((D.ntrain * nxn + 7) / 8) * (nslab32 / nxn);
+    hipLaunchKernelGGL((k_backward_tp<256>), dim3(grid, n_seeds), dim3(512), 2 * bwd_smem_bytes(true, 256), st, dD, a, c,
+                       nslab32, D.ntrain, nxn);
+    return hipGetLastError();
+  }
   const int pw = bwd_parts_per_wg(D.B, D.H, n_seeds);
   const int grid = 8 * ((layer2_parts(D.H) / pw * D.ntrain + 7) / 8) * (D.B / SLAB);
   const size_t sm = bwd_smem_bytes(bf16, D.H);

@@ -314,6 +314,11 @@ class MLP(nn.Module):
         self._out_act = 0 if output_activation_fn is None else 1
         self._squeeze = squeeze_output
         self._dropout = dropout
+        # key of this module's stand-alone dropout masks: the torch seed in force when the module was
+        # BUILT (train(seeds_per_gpu=K) builds the K actors after K successive set_seed calls: each
+        # keeps its own run's seed, as it would running alone).  The per-module call counter is
+        # neither checkpointed nor reset: a resumed run draws its masks from call 0 again.
+        self._drop_seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
 
     def linears(self) -> List[nn.Linear]:
         return [m for m in self.net if isinstance(m, nn.Linear)]
@@ -324,10 +329,9 @@ class MLP(nn.Module):
         if self._dropout is not None and self.training and self._dropout > 0:
             # a module in train mode applies its Dropout layers (ref:436-437; GaussianPolicy.act in
             # train mode samples through them, ref:476-482): masks from the library's Philox stream
-            # keyed by the torch seed, a fresh one per call
+            # keyed by the torch seed the module was built under, a fresh one per call
             self._drop_calls = getattr(self, "_drop_calls", 0) + 1
-            drop = (float(self._dropout), torch.initial_seed() & 0xFFFFFFFFFFFFFFFF,
-                    (self._drop_calls - 1) & 0xFFFFFFFF)
+            drop = (float(self._dropout), self._drop_seed, (self._drop_calls - 1) & 0xFFFFFFFF)
         y = mlp_forward_f32([l.weight for l in lin], [l.bias for l in lin], x,
                             w_in_out=False, hidden_act=self._hidden_act, out_act=self._out_act, dropout=drop)
         return y.squeeze(-1) if self._squeeze else y

@@ -206,7 +206,9 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
           action_dim: Optional[int] = None, max_action: Optional[float] = None,
           logger: Optional[Callable[[Dict[str, float], int], None]] = None,
           evaluate: Optional[Callable] = None, precision: str = "bf16",
-          raw_dataset=None, host_prep: bool = False, seeds_per_gpu: int = 1):
+          raw_dataset=None, host_prep: bool = False, seeds_per_gpu: int = 1,
+          vector_env: Optional[Callable] = None,
+          index_stream: Optional[Callable[[int, int, int], torch.Tensor]] = None):
     """ref:1393-1570.  ``dataset``: an already-built qlearning dataset (skips d4rl);
     ``raw_dataset``: an env.get_dataset()-style dict handed to the relabel functions;
     ``evaluate(actor, step) -> (scores, steps_to_goal)`` replaces eval_actor when gym is
@@ -225,7 +227,14 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
     (iql_eval.py:143-146: the reward model is tied to the seed) every seed trains on its own
     relabelled dataset, otherwise all share one device buffer.  Records of the loggers carry a
     ``seed`` entry; the metric all-gather carries K x world records.  Returns the list of K
-    trainers (the single trainer when K = 1)."""
+    trainers (the single trainer when K = 1).
+
+    ``vector_env``: the environment factory handed to ``eval_actor`` (default: gym's AsyncVectorEnv);
+    given one, evaluation runs through ``eval_actor`` even without a gym ``env``.
+    ``index_stream(slot, first_step, n) -> int64 [n, batch_size]`` (tests): the replay rows of steps
+    ``first_step .. first_step + n - 1`` of seed slot ``slot`` instead of the on-device Philox
+    stream -- how a run of the reference's own ``train()`` (whose sampler draws from torch's global
+    CPU generator, ref:212-214) is replayed step for step."""
     # one process per GPU: under torchrun this rank owns cuda:<LOCAL_RANK>, and everything
     # below (process group, buffer, trainer, metric all-gather) lives there
     bound = D.local_device()
@@ -245,7 +254,10 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
 
     # ---- datasets: one per seed when the reward model is tied to the seed, else one for all ----
     source = dataset if dataset is not None else raw_dataset
-    per_seed_data = bool(config.reward_model_root) and K > 1
+    # iql_eval.py:143-146 ties the reward model to the RUN's seed: rank r / slot k trains seed
+    # seeds[k] on the dataset relabelled by f"{root}_{seeds[k]}" -- also with one seed per GPU (under
+    # torchrun rank r > 0 trains config.seed + r, not the seed TrainConfig.__post_init__ saw)
+    per_seed_data = bool(config.reward_model_root)
     buffers, stats = [], []
     for k in range(K if per_seed_data else 1):
         cfg_k = config
@@ -274,6 +286,10 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
             ckpt_dirs[k] = config.checkpoints_path if K == 1 else os.path.join(config.checkpoints_path, f"seed_{seeds[k]}")
             os.makedirs(ckpt_dirs[k], exist_ok=True)
 
+    if K > 1 and config.load_model != "":
+        import warnings
+        warnings.warn(f"seeds_per_gpu={K} with load_model set: all {K} seeds start from the SAME checkpoint "
+                      f"({config.load_model}) and differ only in their sample streams", stacklevel=2)
     trainers = [_build_trainer(config, seeds[k], state_dim, action_dim, max_action, precision) for k in range(K)]
     group = None
     if K > 1:
@@ -302,10 +318,14 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
         # run to the next logging / evaluation boundary in one library call (ref:1533-1544)
         nxt = min(total, (t // config.log_freq + 1) * config.log_freq,
                   (t // config.eval_freq + 1) * config.eval_freq)
+        idx = None
+        if index_stream is not None:
+            idx = [index_stream(k, t, nxt - t).to(device=config.device, dtype=torch.int64) for k in range(K)]
         if group is None:
-            losses = [trainers[0].train_steps(buffers[0], nxt - t, config.batch_size)]
+            losses = [trainers[0].train_steps(buffers[0], nxt - t, config.batch_size,
+                                              indices=None if idx is None else idx[0])]
         else:
-            losses = group.train_steps(buffers, nxt - t, config.batch_size, return_losses=True)
+            losses = group.train_steps(buffers, nxt - t, config.batch_size, return_losses=True, indices=idx)
         for k in range(K):
             windows[k] = losses[k] if t % config.log_freq == 0 else torch.cat([windows[k], losses[k]])
         t = nxt
@@ -326,10 +346,11 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
                 actor = trainer.actor
                 if evaluate is not None:
                     scores, steps_to_goal = evaluate(actor, t)
-                elif env is not None and hasattr(env, "spec"):
+                elif vector_env is not None or (env is not None and hasattr(env, "spec")):
                     # the evaluation seed of a run is the run's own seed (ref:1547-1556)
                     scores, steps_to_goal = eval_actor(config.env, actor, max_action, stats[k][0], stats[k][1],
-                                                       config.device, config.n_episodes, seeds[k])
+                                                       config.device, config.n_episodes, seeds[k],
+                                                       vector_env=vector_env)
                 else:
                     scores, steps_to_goal = None, []
                 if scores is not None:

@@ -53,7 +53,22 @@ class _Dynamics:
         return self.state.copy(), reward, done
 
 
+class _Box:
+    """The fields of a gym Box space the training entry points read (ref:1400-1401, 1458, 232-233)."""
+
+    def __init__(self, n, high=1.0):
+        self.shape, self.high, self.low = (n,), np.full(n, high), np.full(n, -high)
+        self.seeded = None
+
+    def seed(self, seed):
+        self.seeded = seed
+
+
 class FakeGymEnv(_Dynamics):
+    def __init__(self, name):
+        super().__init__(name)
+        self.observation_space, self.action_space = _Box(self.S, np.inf), _Box(self.A, 1.0)
+
     def seed(self, seed):
         self._seed(seed)
 

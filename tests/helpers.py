@@ -75,6 +75,19 @@ def regen_inputs(d):
     return data, nets
 
 
+def regen_indices(d):
+    """The index stream of a seed-regenerated trajectory: make_fixtures.run_trajectory draws
+    torch.randint(0, n_rows, (batch,)) from torch.Generator().manual_seed(seed + 1) per step."""
+    import torch
+    h = d["hyper"]
+    B, n, K = int(h[3]), int(h[4]), int(h[5])
+    g = torch.Generator().manual_seed(int(d["regen_seed"]) + 1)
+    idx = np.stack([torch.randint(0, n, (B,), generator=g).numpy() for _ in range(K)])
+    if "check/indices" in getattr(d, "files", d) and not np.array_equal(tensor_checks(idx), d["check/indices"]):
+        raise AssertionError("regenerated index stream is not the one the reference run drew")
+    return idx
+
+
 def load_traj(name, mode):
     d = np.load(os.path.join(GOLDEN, f"{name}_{mode}.npz"))
     common = d
@@ -115,3 +128,25 @@ def golden_param(d, key, arr):
     if key + "#stride37" in d.files:
         return d[key + "#stride37"], np.asarray(arr).reshape(-1)[::37]
     return None, None
+
+
+def resume_state(d):
+    """The reference's checkpoint after `ckpt/total_it` steps out of a traj_resume_* fixture:
+    (qf, vf, actor, q_target) parameter dicts, {group: {param name: (exp_avg, exp_avg_sq)}} with the
+    parameter names in the reference's optimizer order, the step count."""
+    pick = lambda pre: {k[len(pre):]: d[k] for k in d.files if k.startswith(pre)}
+    nets = (pick("ckpt/qf/"), pick("ckpt/vf/"), pick("ckpt/actor/"))
+    target = pick("ckpt/q_target/")
+    moments = {}
+    for group, opt, net in (("q", "q_optimizer", nets[0]), ("v", "v_optimizer", nets[1]),
+                            ("actor", "actor_optimizer", nets[2])):
+        names = list(net.keys())  # state_dict order = named_parameters order = the optimizer's index order
+        if group == "actor" and "log_std" in names:  # (registered first in GaussianPolicy: index 0 either way)
+            assert names[0] == "log_std" or names[-1] == "log_std"
+        assert int(d[f"ckpt/{opt}/n_params"]) == len(names)
+        moments[group] = {n: (d[f"ckpt/{opt}/{i}/exp_avg"], d[f"ckpt/{opt}/{i}/exp_avg_sq"])
+                          for i, n in enumerate(names)}
+        for i, n in enumerate(names):
+            assert d[f"ckpt/{opt}/{i}/exp_avg"].shape == net[n].shape, (opt, i, n)
+            assert float(d[f"ckpt/{opt}/{i}/step"]) == float(d["ckpt/total_it"])
+    return nets, target, moments, int(d["ckpt/total_it"])

@@ -165,3 +165,62 @@ def test_ensemble_oracle_matches_twinq_and_its_own_gradient():
         lo[key][ix] -= eps
         fd = (loss(hi) - loss(lo)) / (2 * eps)
         np.testing.assert_allclose(grads[key][ix], fd, rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_oracle_resumes_reference_checkpoint(mode):
+    """Long-horizon arithmetic without free-running chaos: the reference's state after 990 steps
+    (its checkpoint dict + target net, traj_resume_*) loaded into the oracle, then the reference's
+    next 10 batches: Adam bias corrections at t ~ 1000, cosine lr mid-schedule (max_steps 2000),
+    Polyak -- losses and final parameters meet the reference's run."""
+    d = np.load(f"{helpers.GOLDEN}/traj_resume_{mode}.npz")
+    h = d["hyper"]
+    hyper = dict(s_dim=int(h[0]), a_dim=int(h[1]), hidden=int(h[2]), batch=int(h[3]), n_rows=int(h[4]),
+                 k_steps=int(h[5]), beta=float(h[6]), iql_tau=float(h[7]), discount=float(h[8]), tau=float(h[9]),
+                 deterministic=bool(h[10]), dropout=None, max_steps=int(h[12]))
+    data, _ = helpers.regen_inputs(d)
+    idx = helpers.regen_indices(d)
+    nets, target, moments, t0 = helpers.resume_state(d)
+    o = helpers.make_oracle(hyper, nets, mode)
+    o.q_target = {k: v.copy() for k, v in target.items()}
+    o.total_it = t0
+    for g in ("q", "v", "actor"):
+        for n, (m, v2) in moments[g].items():
+            o.m[g][n], o.v2[g][n] = m.copy(), v2.copy()
+    o.lr["actor"] = orc.cosine_lr(3e-4, t0, hyper["max_steps"])
+    sch = d["ckpt/actor_lr_schedule"]  # T_max, eta_min, base_lr, last_epoch, _step_count, _last_lr
+    assert sch[0] == hyper["max_steps"] and sch[3] == t0 and abs(sch[5] - o.lr["actor"]) < 1e-15
+    ltol = 1e-5 if mode == "fp32" else 2e-3  # (as test_trajectory_matches_reference at H < 256)
+    for t in range(t0, hyper["k_steps"]):
+        assert abs(o.lr["actor"] - d["actor_lr"][t]) <= 1e-12 * d["actor_lr"][t]
+        out = o.train(orc.gather_batch(data, idx[t]))
+        np.testing.assert_allclose([out["value_loss"], out["q_loss"], out["actor_loss"]], d["losses"][t], rtol=ltol)
+    ptol = 1e-6 if mode == "fp32" else 2e-5
+    for net, pd in (("qf", o.qf), ("vf", o.vf), ("actor", o.actor), ("q_target", o.q_target)):
+        for k, v in pd.items():
+            np.testing.assert_allclose(v, d[f"final/{net}/{k}"], atol=ptol, rtol=0, err_msg=f"{net}/{k}")
+    for which, net in (("q", "q_adam"), ("v", "v_adam"), ("actor", "actor_adam")):
+        for k, m in o.m[which].items():
+            want = d[f"final/{net}/{k}/exp_avg"]
+            assert np.abs(m - want).max() <= (2e-5 if mode == "fp32" else 2e-2) * (np.abs(want).max() + 1e-30)
+            assert float(d[f"final/{net}/{k}/step"]) == hyper["k_steps"]
+
+
+def test_train_run_fixture_is_selfconsistent():
+    """tests/golden/train_runs.npz (the reference's own train(), ref:1393-1570): the schedule the
+    reference followed -- log windows at 20 / 40 / 60, evaluations + checkpoints at 30 / 60 named
+    after the 0-based step, wandb.log(step=total_it), the loss window logged before the evaluation
+    of the same step -- and the TrainConfig fields its wandb.init received are ours."""
+    import dataclasses
+    import iqlpref_amd as ia
+    d = np.load(f"{helpers.GOLDEN}/train_runs.npz")
+    ours = {f.name for f in dataclasses.fields(ia.TrainConfig)}
+    for tag in ("antmaze_bf16", "antmaze_fp32", "cheetah_bf16"):
+        assert list(d[f"{tag}/log_steps"]) == [20, 30, 40, 60, 60]
+        keys = list(d[f"{tag}/log_keys"])
+        assert keys[0] == keys[2] == keys[3] == "value_loss|q_loss|actor_loss"
+        assert keys[1] == keys[4] == ("mean_score|avg_steps_to_goal" if "antmaze" in tag else "mean_score")
+        assert list(d[f"{tag}/checkpoint_files"]) == ["checkpoint_29.pt", "checkpoint_59.pt", "config.yaml"]
+        assert int(d[f"{tag}/ckpt/checkpoint_29.pt/total_it"]) == 30 and int(d[f"{tag}/total_it"]) == 60
+        assert set(d[f"{tag}/wandb_config_keys"]) <= ours
+        assert d[f"{tag}/indices"].shape == (60, 256)

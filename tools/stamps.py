@@ -24,7 +24,10 @@ data = bench.synth_dataset(1, 200_000)
 buf = ia.ReplayBuffer(bench.S_DIM, bench.A_DIM, 200_000, dev)
 buf.load_d4rl_dataset(data)
 prec = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "bf16"
-tr = bench.build_trainer(ia, torch, dev, 1, prec)
+# STAMP_E / STAMP_B: critics and batch of the stamped configuration (default: the headline's 2 / 256)
+_E, _B = int(os.environ.get("STAMP_E", "2")), int(os.environ.get("STAMP_B", str(bench.BATCH)))
+bench.BATCH = _B
+tr = bench.build_trainer(ia, torch, dev, 1, prec, n_critics=_E)
 # STAMP_GROUP=K: the stamped trainer is member 0 of a seed group of K (one launch sequence,
 # gridDim.y = K): the timeline of ITS work-groups inside the group launches
 _K = int(os.environ.get("STAMP_GROUP", "1"))
@@ -34,7 +37,7 @@ dbg_all = [dbg]
 if _K > 1:
     # the group copies its members' descriptors when it is created: attach the buffers first
     # (every member gets its own: STAMP_ALL=1 prints when each member's work-groups ran)
-    members = [tr] + [bench.build_trainer(ia, torch, dev, 1 + i, prec) for i in range(1, _K)]
+    members = [tr] + [bench.build_trainer(ia, torch, dev, 1 + i, prec, n_critics=_E) for i in range(1, _K)]
     dbg_all = [dbg] + [torch.zeros_like(dbg) for _ in range(1, _K)]
     for t_, d_ in zip(members, dbg_all):
         t_._ensure_handle(bench.BATCH)
