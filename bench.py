@@ -64,17 +64,136 @@ def synth_dataset(seed, n=N_ROWS):
     }
 
 
-def build_trainer(ia, torch, device, seed, precision, n_critics=2):
+def build_trainer(ia, torch, device, seed, precision, n_critics=2, dims=None, dropout=None, hyper=None):
+    S, A = dims or (S_DIM, A_DIM)
     torch.manual_seed(seed)
-    q = (ia.TwinQ(S_DIM, A_DIM) if n_critics == 2 else ia.EnsembleQ(S_DIM, A_DIM, n_critics=n_critics)).to(device)
-    v = ia.ValueFunction(S_DIM).to(device)
-    actor = ia.GaussianPolicy(S_DIM, A_DIM, 1.0).to(device)
+    q = (ia.TwinQ(S, A) if n_critics == 2 else ia.EnsembleQ(S, A, n_critics=n_critics)).to(device)
+    v = ia.ValueFunction(S).to(device)
+    actor = ia.GaussianPolicy(S, A, 1.0, dropout=dropout).to(device)
     vo = torch.optim.Adam(v.parameters(), lr=3e-4)
     qo = torch.optim.Adam(q.parameters(), lr=3e-4)
     ao = torch.optim.Adam(actor.parameters(), lr=3e-4)
     return ia.ImplicitQLearning(
         max_action=1.0, actor=actor, actor_optimizer=ao, q_network=q, q_optimizer=qo,
-        v_network=v, v_optimizer=vo, device=device, precision=precision, seed=seed, **HYPER)
+        v_network=v, v_optimizer=vo, device=device, precision=precision, seed=seed, **(hyper or HYPER))
+
+
+# BASELINE configs[2] (pen-human-v1, configs/offline/iql/pen/human_v1.yaml: actor_dropout 0.1, beta 3,
+# iql_tau 0.8, batch 256; 25 episodes x 200 transitions): the training step of the config whose
+# relabel half is the `pt_pen_config3` entry of the relabel leg
+PEN = dict(dims=(45, 24), n_rows=5_000, dropout=0.1,
+           hyper=dict(beta=3.0, iql_tau=0.8, discount=0.99, tau=0.005, max_steps=1_000_000))
+
+
+def synth_dataset_dims(seed, n, S, A):
+    rng = np.random.default_rng(seed)
+    return {"observations": rng.standard_normal((n, S), dtype=np.float32),
+            "actions": rng.uniform(-1, 1, (n, A)).astype(np.float32),
+            "rewards": rng.standard_normal(n).astype(np.float32),
+            "next_observations": rng.standard_normal((n, S), dtype=np.float32),
+            "terminals": (rng.uniform(size=n) < 5e-3).astype(np.float32)}
+
+
+PROFILE_TAG = os.environ.get("IQL_PROFILE_TAG", "r04")
+
+
+def profile_kernel_avg(fname, *needles):
+    """AverageNs of the first kernel whose name contains every needle, out of a committed rocprofv3
+    --kernel-trace --stats summary under profiles/ (None when the file or the kernel is missing)."""
+    import csv
+    path = os.path.join(ROOT, "profiles", fname)
+    if not os.path.exists(path):
+        return None
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if all(n in row.get("Name", "") for n in needles):
+                return {"kernel": row["Name"].split("(")[0].replace("void iqlhip::", ""), "calls": int(row["Calls"]),
+                        "kernel_avg_ns": float(row["AverageNs"])}
+    return None
+
+
+def profile_build(tag=None):
+    """Build tag of the library the committed profile set <tag> was collected on
+    (profiles/<tag>_meta.json; sets older than round 4 carry it in <tag>_traffic.json only)."""
+    for name in (f"{tag or PROFILE_TAG}_meta.json", f"{tag or PROFILE_TAG}_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                return json.load(f).get("build")
+    return None
+
+
+def roofline_block(kernel, bytes_launch, live_us, live_mode, prof_file, prof_needles, prof_mode, build, extra=None):
+    """`roofline` of a leg.  `frac` / `achieved` follow from the COMMITTED rocprofv3 summary
+    (profiles/<prof_file>: algorithmic bytes per launch / the kernel's average duration there), so a
+    reader can recompute them from tracked files; the figure measured live in this run (HIP events on
+    the launch stream) stands beside it under `live` with its own launch mode."""
+    live = {"launch_us": live_us, "achieved": bytes_launch / (live_us * 1e-6) / 1e9 if live_us else None,
+            "launch_mode": live_mode}
+    live["frac"] = live["achieved"] / HBM_PEAK_GBS if live["achieved"] else None
+    out = {"kernel": kernel, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "algorithmic_bytes_per_launch": bytes_launch, "live": live}
+    # (prof_file names this round's set; until it is committed the last round's file of the same kind
+    # is used and labelled: matches_this_build says whether it was collected on the library running now)
+    pk, ptag = None, None
+    for ptag in (PROFILE_TAG, "r03"):
+        cand = prof_file.replace(PROFILE_TAG + "_", ptag + "_", 1)
+        pk = profile_kernel_avg(cand, *prof_needles)
+        if pk is not None:
+            prof_file = cand
+            break
+    if pk is not None:
+        ach = bytes_launch / (pk["kernel_avg_ns"] * 1e-9) / 1e9
+        pb = profile_build(ptag)
+        out["from_profile"] = dict(pk, file=f"profiles/{prof_file}", achieved=ach, frac=ach / HBM_PEAK_GBS,
+                                   launch_mode=prof_mode, build=pb, matches_this_build=(pb == build))
+        out["achieved"], out["frac"], out["frac_source"] = ach, ach / HBM_PEAK_GBS, f"profiles/{prof_file}"
+    else:
+        out["achieved"], out["frac"], out["frac_source"] = live["achieved"], live["frac"], "live (no committed profile)"
+    if extra:
+        out.update(extra)
+    return out
+
+
+def kernel_times(_lib, tr, buf, batch, n=300):
+    """HIP-event time of each of the three kernels of a step (diagnostic pass of the library), us."""
+    import ctypes as C
+    lib = _lib.load()
+    _lib.check(lib.iqlhip_trainer_set_timing(tr._handle, 1))
+    tr.train_steps(buf, n, batch, return_losses=False, graph_unroll=0)
+    avg, nl = (C.c_double * 3)(), C.c_int64()
+    _lib.check(lib.iqlhip_trainer_get_timing(tr._handle, C.byref(avg), C.byref(nl)))
+    _lib.check(lib.iqlhip_trainer_set_timing(tr._handle, 0))
+    return [avg[k] * 1e3 for k in range(3)], int(nl.value)
+
+
+def step_leg(ia, torch, _lib, tr, buf, batch, n_steps, unroll, prof_file, prof_needles, label):
+    """steps/s of one trainer + its roofline block (dominant kernel k_update, algorithmic bytes of
+    iqlhip_step_cost minus the gather term)."""
+    import ctypes as C
+    tr.train_steps(buf, max(200, n_steps // 5), batch, return_losses=False, graph_unroll=unroll)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    tr.train_steps(buf, n_steps, batch, return_losses=False, graph_unroll=unroll)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    by, fl = C.c_double(), C.c_double()
+    cfg = tr._cfg(batch)
+    _lib.check(_lib.load().iqlhip_step_cost(C.byref(cfg), C.byref(by), C.byref(fl)))
+    ev, _ = kernel_times(_lib, tr, buf, batch, 200)
+    step_us = dt / n_steps * 1e6
+    scale = step_us / sum(ev) if sum(ev) > 0 else 1.0
+    gather = 4.0 * batch * (2 * cfg.state_dim + cfg.action_dim + 2)
+    mode = f"hipGraphs of {unroll} steps" if unroll else "plain launches"
+    rf = roofline_block(label, by.value - gather, ev[2] * scale, mode + "; HIP-event shares scaled to tile the step",
+                        prof_file, prof_needles, "hipGraphs of 50 steps under rocprofv3 --kernel-trace", _lib.build_tag(),
+                        extra={"step": {"bytes_per_step": by.value, "us_per_step": step_us,
+                                        "achieved_gbs": by.value / (step_us * 1e-6) / 1e9,
+                                        "frac": by.value / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                        "kernel_us_events_only": {"k_forward": ev[0], "k_backward": ev[1], "k_update": ev[2]},
+                                        "mfma_tflops": fl.value / (step_us * 1e-6) / 1e12,
+                                        "mfma_peak_tflops": MFMA_BF16_PEAK_TFLOPS}})
+    return {"value": n_steps / dt, "unit": "steps/s", "us_per_step": step_us, "roofline": rf}
 
 
 def cpu_baseline(data, seconds=12.0):
@@ -181,6 +300,7 @@ def main():
                          "the GPU -- the reference launcher's AGENTS_PER_GPU "
                          "(ensemble_sweeps/launch.sh:12); 0 disables.  `value` is always 1 seed per GPU")
     ap.add_argument("--no-relabel", action="store_true", help="skip the reward-relabel leg (N=1 only)")
+    ap.add_argument("--no-pen", action="store_true", help="skip the config-3 (pen shapes + dropout) training leg (N=1 only)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -313,10 +433,12 @@ def main():
         ev_us = [avg[k] * 1e3 for k in range(3)]
         scale = step_us_dev / sum(ev_us) if sum(ev_us) > 0 else 1.0
         upd_us = ev_us[2] * scale
-        achieved = upd_bytes / (upd_us * 1e-6) / 1e9  # GB/s of k_update
         traffic, traffic_src = None, None
-        tname = os.environ.get("IQL_TRAFFIC_PROFILE", "r03_traffic.json")
+        tname = os.environ.get("IQL_TRAFFIC_PROFILE", f"{PROFILE_TAG}_traffic.json")
         tpath = os.path.join(ROOT, "profiles", tname)
+        if not os.path.exists(tpath):  # (no set of this round yet: the last committed one, labelled as such)
+            tname = "r03_traffic.json"
+            tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):  # PMC passes (separate rocprofv3 --pmc runs, tools/profile.sh)
             with open(tpath) as f:
                 tj = json.load(f)
@@ -325,6 +447,23 @@ def main():
                            "note": "PMC (2*FETCH_SIZE + WRITE_SIZE) of an earlier rocprofv3 run of this "
                                    "command; not collected in this timed run",
                            "matches_this_build": tj.get("build") == _lib.build_tag()}
+        live_mode = (f"hipGraphs of {unroll} steps" if unroll else "plain kernel launches from the library's C loop") + \
+            "; HIP-event shares of 300 eager steps scaled to tile the measured device time per step"
+        roof = roofline_block("k_update", upd_bytes, upd_us, live_mode, f"{PROFILE_TAG}_kernel_stats.csv",
+                              ("k_update<true, true>",), "hipGraphs of 50 steps under rocprofv3 --kernel-trace --stats "
+                              "(plain launches are paced by the tracer's per-dispatch interception)", _lib.build_tag(),
+                              extra={"traffic": traffic, "traffic_source": traffic_src,
+                                     "launch_us": upd_us, "launch_us_events_only": ev_us[2], "launches_timed": int(nl.value),
+                                     "step": {"bytes_per_step": bytes_step.value, "device_us_per_step": step_us_dev,
+                                              "achieved_gbs": bytes_step.value / (step_us_dev * 1e-6) / 1e9,
+                                              "frac": bytes_step.value / (step_us_dev * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                              "kernel_us": {"k_forward": ev_us[0] * scale, "k_backward": ev_us[1] * scale,
+                                                            "k_update": ev_us[2] * scale},
+                                              "kernel_us_events_only": {"k_forward": ev_us[0], "k_backward": ev_us[1],
+                                                                        "k_update": ev_us[2]},
+                                              "mfma_tflops": flops_step.value / (step_us_dev * 1e-6) / 1e12,
+                                              "mfma_peak_tflops": MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16"
+                                              else MFMA_F32_PEAK_TFLOPS}})
         out = {
             "metric": "iql_grad_steps_per_sec", "value": steps_per_s, "unit": "steps/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -343,23 +482,7 @@ def main():
                        "note": "each block = K steps between barrier+synchronize pairs; median block, "
                                "max over ranks; *_device = HIP events on the launch stream"},
             "build": _lib.build_tag(),
-            "roofline": {
-                "kernel": "k_update", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": upd_bytes, "launch_us": upd_us,
-                "launch_us_events_only": ev_us[2], "launches_timed": int(nl.value),
-                "step": {"bytes_per_step": bytes_step.value, "device_us_per_step": step_us_dev,
-                         "achieved_gbs": bytes_step.value / (step_us_dev * 1e-6) / 1e9,
-                         "frac": bytes_step.value / (step_us_dev * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "kernel_us": {"k_forward": ev_us[0] * scale, "k_backward": ev_us[1] * scale,
-                                       "k_update": ev_us[2] * scale},
-                         "kernel_us_events_only": {"k_forward": ev_us[0], "k_backward": ev_us[1],
-                                                   "k_update": ev_us[2]},
-                         "mfma_tflops": flops_step.value / (step_us_dev * 1e-6) / 1e12,
-                         "mfma_peak_tflops": MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16"
-                         else MFMA_F32_PEAK_TFLOPS},
-            },
+            "roofline": roof,
         }
         if recs is not None:
             out["ranks"] = recs
@@ -389,19 +512,30 @@ def main():
             try:
                 E_ = args.ensemble_q
                 tre = build_trainer(ia, torch, device, seed + 50, args.precision, n_critics=E_)
-                tre.train_steps(buf, 1_000, 1024, return_losses=False, graph_unroll=50)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                n_e = 5_000
-                tre.train_steps(buf, n_e, 1024, return_losses=False, graph_unroll=50)
-                torch.cuda.synchronize()
-                dt_e = time.perf_counter() - t1
-                out["ensemble_q"] = {"n_critics": E_, "batch": 1024, "value": n_e / dt_e, "unit": "steps/s",
-                                     "transitions_per_s": 1024 * n_e / dt_e,
-                                     "note": "BASELINE configs[4] (E-way critic ensemble, batch 1024); not `value`"}
+                leg = step_leg(ia, torch, _lib, tre, buf, 1024, 5_000, 50, f"{PROFILE_TAG}_ens{E_}_kernel_stats.csv",
+                               ("k_update<true, false>",), f"k_update (E = {E_} critics, batch 1024)")
+                out["ensemble_q"] = dict(leg, n_critics=E_, batch=1024, transitions_per_s=1024 * leg["value"],
+                                         note="BASELINE configs[4] (E-way critic ensemble, batch 1024, antmaze "
+                                              "shapes); not `value`")
                 del tre
             except Exception as e:
                 out["ensemble_q"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_pen:
+            try:
+                S_, A_ = PEN["dims"]
+                bufp = ia.ReplayBuffer(S_, A_, PEN["n_rows"], device)
+                bufp.load_d4rl_dataset(synth_dataset_dims(seed + 70, PEN["n_rows"], S_, A_))
+                trp = build_trainer(ia, torch, device, seed + 70, args.precision, dims=PEN["dims"],
+                                    dropout=PEN["dropout"], hyper=PEN["hyper"])
+                leg = step_leg(ia, torch, _lib, trp, bufp, BATCH, 20_000, 0, f"{PROFILE_TAG}_pen_kernel_stats.csv",
+                               ("k_update<true, true>",), "k_update (pen shapes S=45 A=24, actor dropout 0.1)")
+                out["pen_config3"] = dict(leg, batch=BATCH, buffer_rows=PEN["n_rows"],
+                                          note="BASELINE configs[2] training step (pen-human-v1 shapes and hyper-"
+                                               "parameters, Philox dropout masks); its relabel half is "
+                                               "relabel.pt_pen_config3; not `value`")
+                del trp, bufp
+            except Exception as e:
+                out["pen_config3"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_relabel:
             try:
                 from tools import bench_relabel
@@ -500,15 +634,15 @@ def agents_leg(ia, torch, tr, buf, device, seed, args, unroll, bytes_step):
         step_us = A_ / v_group * 1e6
         scale = step_us / sum(ev) if sum(ev) > 0 else 1.0
         upd_bytes = A_ * (bytes_step - 4.0 * BATCH * (2 * S_DIM + A_DIM + 2))
-        upd_us = ev[2] * scale
-        out["roofline"] = {"kernel": "k_update (gridDim.y = %d, one group on the whole chip)" % A_, "bound": "hbm",
-                           "achieved": upd_bytes / (upd_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": upd_bytes / (upd_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                           "algorithmic_bytes_per_launch": upd_bytes, "launch_us": upd_us,
-                           "group_step_us": step_us,
-                           "kernel_us": {"k_forward": ev[0] * scale, "k_backward": ev[1] * scale,
-                                         "k_update": ev[2] * scale},
-                           "kernel_us_events_only": {"k_forward": ev[0], "k_backward": ev[1], "k_update": ev[2]}}
+        from iqlpref_amd import _lib as _l
+        out["roofline"] = roofline_block(
+            "k_update (gridDim.y = %d, one group on the whole chip)" % A_, upd_bytes, ev[2] * scale,
+            f"hipGraphs of {u} steps; HIP-event shares scaled to tile the group step", f"{PROFILE_TAG}_group{A_}_kernel_stats.csv",
+            ("k_update<true, false>",), "hipGraphs of 50 steps under rocprofv3 --kernel-trace --stats (tools/group_scan.py)",
+            _l.build_tag(),
+            extra={"group_step_us": step_us,
+                   "kernel_us": {"k_forward": ev[0] * scale, "k_backward": ev[1] * scale, "k_update": ev[2] * scale},
+                   "kernel_us_events_only": {"k_forward": ev[0], "k_backward": ev[1], "k_update": ev[2]}})
     group.close()
     return out
 

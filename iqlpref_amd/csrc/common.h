@@ -142,6 +142,16 @@ __device__ __forceinline__ T xor32_sum(T v) {  // v[lane] + v[lane ^ 32]
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
   return a + b;
 }
+// v_permlane16_swap_b32 a, b: rows 1 and 3 of a (a row = 16 lanes) trade places with rows 0 and 2 of b.
+// With a, b = the packed C-layout registers of two 16-row MFMA tiles that are neighbours along the
+// row dimension, a lane of an even row then holds [its own 4 rows of tile a | the next 4 rows of
+// tile a] and a lane of an odd row the same of tile b: 16 contiguous bytes per lane of a feature-major
+// image, ONE 16-byte store where the plain epilogue issues two 8-byte ones -- these epilogues are
+// bound by the number of store instructions, not by their bytes (MI355X_MICROARCH "store tail").
+__device__ __forceinline__ void permlane16_swap(uint32_t &a, uint32_t &b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
 // sum over aligned groups of W consecutive lanes (W a power of two <= 64), result in every lane
 template <int W, class T>
 __device__ __forceinline__ T lane_sum(T v) {

@@ -143,6 +143,18 @@ __device__ __forceinline__ void act_store8(uint16_t *base, size_t elem, uint2 u)
 #endif
 }
 
+// The packed bf16 C-layout registers of two row tiles m (even) and m + 1 of one feature column, stored
+// to a feature-major plane as ONE 16-byte store per lane (permlane16_swap): the lane of row group q
+// ends up with rows 16 (m + (q & 1)) + 4 (q & ~1) .. + 7 of its column.  Same bytes at the same
+// addresses as two act_store8 calls.
+__device__ __forceinline__ void act_store16_pair(uint16_t *plane, int col, int row_m, int q, int nkb, uint2 um,
+                                                 uint2 um1) {
+  permlane16_swap(um.x, um1.x);
+  permlane16_swap(um.y, um1.y);
+  const int k0 = row_m + 16 * (q & 1) + 4 * (q & ~1);
+  stg16(plane + fidx<Prec<true>>(col, k0, nkb), __builtin_bit_cast(float4, make_uint4(um.x, um.y, um1.x, um1.y)));
+}
+
 // relu(round(acc + bias)) of the four batch rows a lane holds for one hidden unit (MFMA C layout),
 // in the compute type.  bf16: relu before the rounding (the same value: rounding is monotone and
 // keeps zero), two values per v_cvt_pk_bf16_f32, no round trip through f32 -- a third of the
@@ -639,16 +651,24 @@ __global__ __launch_bounds__(256, PRE ? 1 : (MT >= 4 ? 2 : 3)) void k_forward(co
       const bool mine = N.train_slot >= 0 && ((tile * SPL) / (4 * TPW)) / PW * PW == part0;
       if (lean) {
         if constexpr (BF16) {
+          uint2 u[MT];
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            const int row0 = slab * ROWS + 16 * m;
-            const uint2 u = relu_bias_bf16x4(acc[m][jj], bias);
+            u[m] = relu_bias_bf16x4(acc[m][jj], bias);
             T *hrow = h1 + (16 * m + 4 * q) * HP + col;
-            hrow[0] = (T)(u.x & 0xffff), hrow[HP] = (T)(u.x >> 16);
-            hrow[2 * HP] = (T)(u.y & 0xffff), hrow[3 * HP] = (T)(u.y >> 16);
-            if (mine && row0 < B)
-              act_store8(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 0) * H * BP,
-                         fidx<P>(col, row0 + 4 * q, BP / P::KM), u);
+            hrow[0] = (T)(u[m].x & 0xffff), hrow[HP] = (T)(u[m].x >> 16);
+            hrow[2 * HP] = (T)(u[m].y & 0xffff), hrow[3 * HP] = (T)(u[m].y >> 16);
+          }
+          T *plane = reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 0) * H * BP;
+          if constexpr (MT >= 2 && !IQL_WT_ACT) {  // (two row tiles = 16 contiguous bytes per lane: one store)
+            if (mine && slab * ROWS + ROWS <= B) {
+#pragma unroll
+              for (int m = 0; m < MT; m += 2) act_store16_pair(plane, col, slab * ROWS + 16 * m, q, BP / P::KM, u[m], u[m + 1]);
+            }
+          } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              if (mine && slab * ROWS + 16 * m < B) act_store8(plane, fidx<P>(col, slab * ROWS + 16 * m + 4 * q, BP / P::KM), u[m]);
           }
         }
         continue;
@@ -706,16 +726,25 @@ __global__ __launch_bounds__(256, PRE ? 1 : (MT >= 4 ? 2 : 3)) void k_forward(co
       T *h2j = h2 + j * ROWS * HQP;
       if (lean) {
         if constexpr (BF16) {
+          uint2 u[MT];
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            const int row0 = slab * ROWS + 16 * m;
-            const uint2 u = relu_bias_bf16x4(acc[j][m], bias);
+            u[m] = relu_bias_bf16x4(acc[j][m], bias);
             T *hrow = h2j + (16 * m + 4 * q) * HQP + 16 * wave + r;
-            hrow[0] = (T)(u.x & 0xffff), hrow[HQP] = (T)(u.x >> 16);
-            hrow[2 * HQP] = (T)(u.y & 0xffff), hrow[3 * HQP] = (T)(u.y >> 16);
-            if (N.train_slot >= 0 && row0 < B)
-              act_store8(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP,
-                         fidx<P>(col, row0 + 4 * q, BP / P::KM), u);
+            hrow[0] = (T)(u[m].x & 0xffff), hrow[HQP] = (T)(u[m].x >> 16);
+            hrow[2 * HQP] = (T)(u[m].y & 0xffff), hrow[3 * HQP] = (T)(u[m].y >> 16);
+          }
+          T *plane = reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP;
+          if constexpr (MT >= 2 && !IQL_WT_ACT) {
+            if (N.train_slot >= 0 && slab * ROWS + ROWS <= B) {
+#pragma unroll
+              for (int m = 0; m < MT; m += 2) act_store16_pair(plane, col, slab * ROWS + 16 * m, q, BP / P::KM, u[m], u[m + 1]);
+            }
+          } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              if (N.train_slot >= 0 && slab * ROWS + 16 * m < B)
+                act_store8(plane, fidx<P>(col, slab * ROWS + 16 * m + 4 * q, BP / P::KM), u[m]);
           }
         }
         continue;
@@ -800,7 +829,7 @@ __global__ __launch_bounds__(256, PRE ? 1 : (MT >= 4 ? 2 : 3)) void k_forward(co
 // fragment requested before the first dependent instruction, one work-group per CU (176 of them
 // for 4 critics at batch 1024, 224 for 8 seeds at batch 256: the whole launch is resident at once).
 // ========================================================================
-template <int H>
+template <int H, bool DROP>
 __global__ __launch_bounds__(512, 1) void k_forward_tp(const TrainerDesc *__restrict__ Dp,
                                                         const DevArgs *__restrict__ Ap,
                                                         const DevCtr *__restrict__ Cp, const int nsl_,
@@ -917,7 +946,10 @@ __global__ __launch_bounds__(512, 1) void k_forward_tp(const TrainerDesc *__rest
   __syncthreads();
   STAMP(0, 2);
 
-  const bool lean = !N.dropout;  // (wave-uniform) see relu_bias_bf16x4
+  // DROP = false: the lean bf16 epilogues only (relu_bias_bf16x4); the instantiation with dropout
+  // carries the Philox masks.  The host picks by the trainer's has_dropout; a network without dropout
+  // inside a DROP launch (every net but the actor) takes the general path with an all-ones mask.
+  const bool store_h = N.train_slot >= 0;  // (wave-uniform) B is a multiple of 64: no row guards
   // ---- hidden layer 1 ----
   {
     f32x4 acc[MT][TPW];
@@ -936,23 +968,31 @@ __global__ __launch_bounds__(512, 1) void k_forward_tp(const TrainerDesc *__rest
         }
       }
     }
+    STAMP(0, 6);
 #pragma unroll
     for (int jj = 0; jj < TPW; ++jj) {
       const int col = 16 * (tile0 + jj) + r;
       const float bias = P::round(bias1[jj]);
+      if constexpr (!DROP) {
+        uint2 u[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          u[m] = relu_bias_bf16x4(acc[m][jj], bias);
+          T *hrow = h1 + (16 * m + 4 * q) * HP + col;
+          hrow[0] = (T)(u[m].x & 0xffff), hrow[HP] = (T)(u[m].x >> 16);
+          hrow[2 * HP] = (T)(u[m].y & 0xffff), hrow[3 * HP] = (T)(u[m].y >> 16);
+        }
+        if (store_h) {
+          T *plane = reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 0) * H * BP;
+#pragma unroll
+          for (int m = 0; m < MT; m += 2)
+            act_store16_pair(plane, col, slab * ROWS + 16 * m, q, BP / P::KM, u[m], u[m + 1]);
+        }
+        continue;
+      }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int row0 = slab * ROWS + 16 * m;
-        if (lean) {
-          const uint2 u = relu_bias_bf16x4(acc[m][jj], bias);
-          T *hrow = h1 + (16 * m + 4 * q) * HP + col;
-          hrow[0] = (T)(u.x & 0xffff), hrow[HP] = (T)(u.x >> 16);
-          hrow[2 * HP] = (T)(u.y & 0xffff), hrow[3 * HP] = (T)(u.y >> 16);
-          if (N.train_slot >= 0 && row0 < B)
-            act_store8(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 0) * H * BP,
-                       fidx<P>(col, row0 + 4 * q, BP / P::KM), u);
-          continue;
-        }
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = fmaxf(P::round(acc[m][jj][i] + bias), 0.f);
@@ -964,7 +1004,7 @@ __global__ __launch_bounds__(512, 1) void k_forward_tp(const TrainerDesc *__rest
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) h1[(16 * m + 4 * q + i) * HP + col] = P::from_f32(v[i]);
-        if (N.train_slot >= 0 && row0 < B)
+        if (store_h)
           store4T<true>(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 0) * H * BP +
                             fidx<P>(col, row0 + 4 * q, BP / P::KM), v);
       }
@@ -989,23 +1029,31 @@ __global__ __launch_bounds__(512, 1) void k_forward_tp(const TrainerDesc *__rest
         for (int jj = 0; jj < TPW; ++jj) P::mma(a, w2[jj][ks], acc[jj][m]);
       }
     }
+    STAMP(0, 7);
 #pragma unroll
     for (int jj = 0; jj < TPW; ++jj) {
       const int col = 16 * (tile0 + jj) + r;
       const float bias = P::round(bias2[jj]);
+      if constexpr (!DROP) {
+        uint2 u[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          u[m] = relu_bias_bf16x4(acc[jj][m], bias);
+          T *hrow = h2 + (16 * m + 4 * q) * HP + col;
+          hrow[0] = (T)(u[m].x & 0xffff), hrow[HP] = (T)(u[m].x >> 16);
+          hrow[2 * HP] = (T)(u[m].y & 0xffff), hrow[3 * HP] = (T)(u[m].y >> 16);
+        }
+        if (store_h) {
+          T *plane = reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP;
+#pragma unroll
+          for (int m = 0; m < MT; m += 2)
+            act_store16_pair(plane, col, slab * ROWS + 16 * m, q, BP / P::KM, u[m], u[m + 1]);
+        }
+        continue;
+      }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int row0 = slab * ROWS + 16 * m;
-        if (lean) {
-          const uint2 u = relu_bias_bf16x4(acc[jj][m], bias);
-          T *hrow = h2 + (16 * m + 4 * q) * HP + col;
-          hrow[0] = (T)(u.x & 0xffff), hrow[HP] = (T)(u.x >> 16);
-          hrow[2 * HP] = (T)(u.y & 0xffff), hrow[3 * HP] = (T)(u.y >> 16);
-          if (N.train_slot >= 0 && row0 < B)
-            act_store8(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP,
-                       fidx<P>(col, row0 + 4 * q, BP / P::KM), u);
-          continue;
-        }
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = fmaxf(P::round(acc[jj][m][i] + bias), 0.f);
@@ -1017,7 +1065,7 @@ __global__ __launch_bounds__(512, 1) void k_forward_tp(const TrainerDesc *__rest
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) h2[(16 * m + 4 * q + i) * HP + col] = P::from_f32(v[i]);
-        if (N.train_slot >= 0 && row0 < B)
+        if (store_h)
           store4T<true>(reinterpret_cast<T *>(g_hT) + (size_t)(N.train_slot * 2 + 1) * H * BP +
                             fidx<P>(col, row0 + 4 * q, BP / P::KM), v);
       }
@@ -1373,10 +1421,35 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
     const bool mine = (c2 / C::HQ) / PW == part;  // the part (group) that owns this hidden unit stores its dZ2
     bool lean = false;
     if constexpr (BF16) lean = !drop_on;  // mask before the rounding (the same value), packed conversion
+    if constexpr (BF16 && !IQL_WT_ACT) {
+      if (lean) {
+        // rows 8 h .. 8 h + 7 of a hidden unit are 16 contiguous bytes of the feature-major plane: two
+        // 16-byte stores per thread instead of four 8-byte ones (store instructions, not bytes, bound
+        // these epilogues)
+#pragma unroll
+        for (int h8 = 0; h8 < 2; ++h8) {
+          uint2 u2[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int g4 = 2 * h8 + e;
+            float t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = h2v[4 * g4 + i] > 0.f ? s[4 * g4 + i] : 0.f;
+            u2[e] = make_uint2(pk_bf16(t[0], t[1]), pk_bf16(t[2], t[3]));
+            T *drow = dz2s + (4 * g4) * HP + c2;
+            drow[0] = (T)(u2[e].x & 0xffff), drow[HP] = (T)(u2[e].x >> 16);
+            drow[2 * HP] = (T)(u2[e].y & 0xffff), drow[3 * HP] = (T)(u2[e].y >> 16);
+          }
+          if (mine)
+            stg16(dst + fidx<P>(c2, slab * SLAB + 8 * h8, nkb),
+                  __builtin_bit_cast(float4, make_uint4(u2[0].x, u2[0].y, u2[1].x, u2[1].y)));
+        }
+      }
+    }
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       if (lean) {
-        if constexpr (BF16) {
+        if constexpr (BF16 && IQL_WT_ACT) {
           float t[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) t[i] = h2v[4 * g4 + i] > 0.f ? s[4 * g4 + i] : 0.f;
@@ -1651,29 +1724,40 @@ __global__ __launch_bounds__(512, 1) void k_backward_tp(const TrainerDesc *__res
       }
     }
     const bool lean = !drop_on;
+    if (lean) {
+      // rows 8 h .. 8 h + 7 of a hidden unit are 16 contiguous bytes of the feature-major plane: two
+      // 16-byte stores per thread instead of four 8-byte ones
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      if (lean) {
-        float t[4];
+      for (int h8 = 0; h8 < 2; ++h8) {
+        uint2 u2[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) t[i] = h2v[4 * g4 + i] > 0.f ? s[4 * g4 + i] : 0.f;
-        const uint2 u = make_uint2(pk_bf16(t[0], t[1]), pk_bf16(t[2], t[3]));
-        T *drow = dz2s + (4 * g4) * HP + c2;
-        drow[0] = (T)(u.x & 0xffff), drow[HP] = (T)(u.x >> 16);
-        drow[2 * HP] = (T)(u.y & 0xffff), drow[3 * HP] = (T)(u.y >> 16);
-        act_store8(dst, fidx<P>(c2, slab * SLAB + 4 * g4, nkb), u);
-        continue;
+        for (int e = 0; e < 2; ++e) {
+          const int g4 = 2 * h8 + e;
+          float t[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t[i] = h2v[4 * g4 + i] > 0.f ? s[4 * g4 + i] : 0.f;
+          u2[e] = make_uint2(pk_bf16(t[0], t[1]), pk_bf16(t[2], t[3]));
+          T *drow = dz2s + (4 * g4) * HP + c2;
+          drow[0] = (T)(u2[e].x & 0xffff), drow[HP] = (T)(u2[e].x >> 16);
+          drow[2 * HP] = (T)(u2[e].y & 0xffff), drow[3 * HP] = (T)(u2[e].y >> 16);
+        }
+        stg16(dst + fidx<P>(c2, slab * SLAB + 8 * h8, nkb),
+              __builtin_bit_cast(float4, make_uint4(u2[0].x, u2[0].y, u2[1].x, u2[1].y)));
       }
-      float outv[4];
+    } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rr = 4 * g4 + i;
-        float sv = P::round(s[rr]);
-        if (drop_on) sv = P::round(sv * drop_scale);
-        outv[i] = h2v[rr] > 0.f ? sv : 0.f;
-        dz2s[rr * HP + c2] = P::from_f32(outv[i]);
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float outv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rr = 4 * g4 + i;
+          float sv = P::round(s[rr]);
+          if (drop_on) sv = P::round(sv * drop_scale);
+          outv[i] = h2v[rr] > 0.f ? sv : 0.f;
+          dz2s[rr * HP + c2] = P::from_f32(outv[i]);
+        }
+        store4T<BF16>(dst + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), outv);
       }
-      store4T<BF16>(dst + fidx<P>(c2, slab * SLAB + 4 * g4, nkb), outv);
     }
   }
   __syncthreads();
@@ -1688,32 +1772,39 @@ __global__ __launch_bounds__(512, 1) void k_backward_tp(const TrainerDesc *__res
   // ---- dZ1 = (dZ2 W2) * relu'(h1)   (MFMA; wave w: n-tiles 2w, 2w + 1 x both slabs) ----
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
+    f32x4 acc[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
       const T *xrow = reinterpret_cast<const T *>(smem + m * SUB_BYTES) + r * HP + P::EPV * q;
 #pragma unroll
       for (int ks = 0; ks < K::NK2; ++ks) {
         const uint4 a = *reinterpret_cast<const uint4 *>(xrow + ks * P::KM);
-        P::mma(a, w2t[t][ks], acc);
+        P::mma(a, w2t[t][ks], acc[m]);
       }
-      const int col = 16 * (tile0 + t) + r;
-      const int row0 = (slab32 * 2 + m) * SLAB;
-      if (!drop_on) {
+    }
+    const int col = 16 * (tile0 + t) + r;
+    if (!drop_on) {
+      uint2 u[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
         float tv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) tv[i] = h1v[t][m][i] > 0.f ? acc[i] : 0.f;
-        act_store8(g_dz1T + (size_t)net * H * BP, fidx<P>(col, row0 + 4 * q, nkb),
-                   make_uint2(pk_bf16(tv[0], tv[1]), pk_bf16(tv[2], tv[3])));
-      } else {
+        for (int i = 0; i < 4; ++i) tv[i] = h1v[t][m][i] > 0.f ? acc[m][i] : 0.f;
+        u[m] = make_uint2(pk_bf16(tv[0], tv[1]), pk_bf16(tv[2], tv[3]));
+      }
+      act_store16_pair(g_dz1T + (size_t)net * H * BP, col, slab32 * 2 * SLAB, q, nkb, u[0], u[1]);
+    } else {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
         float outv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float sv = P::round(acc[i]);
+          float sv = P::round(acc[m][i]);
           sv = P::round(sv * drop_scale);
           outv[i] = h1v[t][m][i] > 0.f ? sv : 0.f;
         }
-        store4T<BF16>(g_dz1T + (size_t)net * H * BP + fidx<P>(col, row0 + 4 * q, nkb), outv);
+        store4T<BF16>(g_dz1T + (size_t)net * H * BP + fidx<P>(col, (slab32 * 2 + m) * SLAB + 4 * q, nkb), outv);
       }
     }
   }
@@ -2631,7 +2722,10 @@ bool use_tp(bool bf16, const TrainerDesc &D, int n_seeds) {
 // once per trainer (iqlhip_trainer_create, outside any stream capture): k_forward_tp's 64-row slabs
 // take more than the 64 KB of dynamic LDS a kernel may use by default
 hipError_t prepare_step_kernels() {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(k_forward_tp<256>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_forward_tp<256, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(k_forward_tp<256, true>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 size_t fwd_tp_smem_bytes(int H, int k1max) { return (size_t)64 * ((k1max + 8) + 2 * (H + 8)) * 2; }
@@ -2643,8 +2737,12 @@ hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD
     const int nsl64 = D.B / 64;
     const int grid = 8 * ((D.nfwd + 1 + 7) / 8) * nsl64;
     // (more than 64 KB of dynamic LDS: allowed by prepare_step_kernels, at trainer creation)
-    hipLaunchKernelGGL((k_forward_tp<256>), dim3(grid, n_seeds), dim3(512), fwd_tp_smem_bytes(256, D.k1max), st, dD, a,
-                       c, nsl64, D.nfwd);
+    if (D.has_dropout)
+      hipLaunchKernelGGL((k_forward_tp<256, true>), dim3(grid, n_seeds), dim3(512), fwd_tp_smem_bytes(256, D.k1max), st,
+                         dD, a, c, nsl64, D.nfwd);
+    else
+      hipLaunchKernelGGL((k_forward_tp<256, false>), dim3(grid, n_seeds), dim3(512), fwd_tp_smem_bytes(256, D.k1max), st,
+                         dD, a, c, nsl64, D.nfwd);
     return hipGetLastError();
   }
   const int mt = fwd_row_tiles(D.B, n_seeds), nsl = (D.B + 16 * mt - 1) / (16 * mt);

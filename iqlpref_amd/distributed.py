@@ -25,6 +25,13 @@ def device_for_rank(local_rank: int, n_visible: int) -> str:
     return f"cuda:{local_rank}"
 
 
+def rehearsal() -> bool:
+    """IQL_DIST_BACKEND=gloo: the multi-rank product path rehearsed on a box with ONE GPU -- every
+    rank on cuda:0, the metric all-gather over gloo with its payload on the host.  The default
+    (unset, or "nccl") is one GPU per rank and RCCL; nothing else differs between the two."""
+    return os.environ.get("IQL_DIST_BACKEND", "nccl").lower() == "gloo"
+
+
 def local_device() -> Optional[str]:
     """Under a torchrun-style launch (WORLD_SIZE > 1): bind this process to its GPU before
     anything else touches a device and return the indexed device string every later object
@@ -32,6 +39,9 @@ def local_device() -> Optional[str]:
     process is not part of a multi-rank job or has no GPU (gloo CPU tests)."""
     if int(os.environ.get("WORLD_SIZE", "1")) <= 1 or not torch.cuda.is_available():
         return None
+    if rehearsal():
+        torch.cuda.set_device(0)
+        return "cuda:0"
     dev = device_for_rank(int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.device_count())
     torch.cuda.set_device(torch.device(dev))
     return dev
@@ -45,7 +55,7 @@ def init_from_env(backend: Optional[str] = None, device: Optional[str] = None) -
     if world <= 1 or dist.is_initialized():
         return dist.get_rank() if dist.is_initialized() else 0
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = "nccl" if (torch.cuda.is_available() and not rehearsal()) else "gloo"
     kw = {}
     if backend == "nccl":
         if device is None or torch.device(device).index is None:
@@ -61,13 +71,20 @@ def rank_seed(base_seed: int, seeds_per_gpu: int = 1) -> int:
     return base_seed + (dist.get_rank() if dist.is_initialized() else 0) * int(seeds_per_gpu)
 
 
+def _payload_device(device: Optional[str]) -> str:
+    """Where a collective's payload lives: the rank's GPU under RCCL, the host under gloo."""
+    if dist.get_backend() != "nccl":
+        return "cpu"
+    return device if device is not None else "cuda"
+
+
 def gather_metrics(record: Dict[str, float], device: Optional[str] = None) -> List[Dict[str, float]]:
     """All-gather one metric record per rank; every rank receives the full list."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     vals = [float(record.get(k, float("nan"))) for k in FIELDS[:-1]] + [float(rank)]
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [dict(zip(FIELDS, vals))]
-    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    dev = _payload_device(device)
     t = torch.tensor(vals, dtype=torch.float64, device=dev)
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
@@ -81,7 +98,7 @@ def gather_metric_records(records: List[Dict[str, float]], device: Optional[str]
     rows = [[float(r.get(k, float("nan"))) for k in FIELDS[:-1]] + [float(rank)] for r in records]
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [dict(zip(FIELDS, row)) for row in rows]
-    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    dev = _payload_device(device)
     t = torch.tensor(rows, dtype=torch.float64, device=dev)
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)

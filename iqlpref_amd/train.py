@@ -153,6 +153,24 @@ def build_dataset(config: TrainConfig, env, dataset=None) -> Dict[str, np.ndarra
     return d4rl.qlearning_dataset(env)
 
 
+def seed_configs(config: TrainConfig, seeds: Sequence[int]) -> List[TrainConfig]:
+    """The config each of this rank's seeds trains under.  iql_eval.py:143-146 ties the reward model
+    to the RUN's seed (``reward_model_path = f"{root}_{seed}"``): with ``reward_model_root`` set, seed s
+    gets its own copy of ``config`` pointing at ``{root}_{s}`` -- for every rank and slot, also with one
+    seed per GPU (under torchrun rank r > 0 trains ``config.seed + r``, not the seed
+    ``TrainConfig.__post_init__`` saw).  Without it all seeds share ``config``."""
+    if not config.reward_model_root:
+        return [config] * len(seeds)
+    import copy
+    out = []
+    for s in seeds:
+        c = copy.copy(config)
+        c.seed = int(s)
+        c.reward_model_path = f"{config.reward_model_root}_{int(s)}"
+        out.append(c)
+    return out
+
+
 def _prepare_replay(config: TrainConfig, dataset, state_dim, action_dim, host_prep: bool):
     """ref:1435-1456: reward normalisation, state statistics, z-scoring, one device buffer."""
     replay_buffer = ReplayBuffer(state_dim, action_dim, config.buffer_size, config.device)
@@ -258,13 +276,10 @@ def train(config: TrainConfig, env=None, dataset=None, *, state_dim: Optional[in
     # seeds[k] on the dataset relabelled by f"{root}_{seeds[k]}" -- also with one seed per GPU (under
     # torchrun rank r > 0 trains config.seed + r, not the seed TrainConfig.__post_init__ saw)
     per_seed_data = bool(config.reward_model_root)
+    cfgs = seed_configs(config, seeds)
     buffers, stats = [], []
     for k in range(K if per_seed_data else 1):
-        cfg_k = config
-        if per_seed_data:
-            import copy
-            cfg_k = copy.copy(config)
-            cfg_k.reward_model_path = f"{config.reward_model_root}_{seeds[k]}"  # iql_eval.py:143-146
+        cfg_k = cfgs[k]
         ds = build_dataset(cfg_k, env, source) if (cfg_k.reward_model_path or dataset is None) else dataset
         if per_seed_data and ds is source:
             ds = {key: np.array(val) for key, val in ds.items()}

@@ -285,3 +285,61 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     # whole-job value = 2 x K steps / the slower rank's block time
     assert abs(rec["value"] - 2 * 20 / (rec["ms_per_step"] * 20 / 1e3)) / rec["value"] < 1e-9
     assert rec["value"] > 2_000  # two ranks sharing one GPU still run thousands of steps/s
+
+
+# ----------------------------------------------------------------------------- #
+# BASELINE configs[3]'s product path, rehearsed on ONE GPU: train() under WORLD_SIZE = 2
+# (ensemble_sweeps/launch.sh:84-94: one process per GPU, each its own seed).  Two fresh child
+# processes (tests/train_rank_child.py) with IQL_DIST_BACKEND=gloo -- both ranks on cuda:0, the
+# metric all-gather over gloo; the default is one GPU per rank and RCCL, nothing else differs.
+# ----------------------------------------------------------------------------- #
+@pytest.mark.parametrize("k_seeds", [1, 2])
+def test_train_two_ranks_on_one_gpu(tmp_path, k_seeds):
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK")}
+    base.update(WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                IQL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "train_rank_child.py"), str(tmp_path),
+                               str(k_seeds)], env=dict(base, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    recs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    K = k_seeds
+    for r, rec in enumerate(recs):
+        # rank r trains seeds base + r K .. base + r K + K - 1 (distributed.rank_seed), all on cuda:0 here
+        assert rec["rank"] == r and rec["device"] == "cuda:0"
+        assert rec["seeds"] == [100 + r * K + k for k in range(K)] and rec["total_it"] == [40] * K
+        loss_logs = [d for _, d in rec["logs"] if "value_loss" in d]
+        eval_logs = [d for _, d in rec["logs"] if "mean_score" in d and "n_seeds" not in d]
+        assert len(loss_logs) == 4 * K and len(eval_logs) == 2 * K
+        if K > 1:
+            assert sorted({int(d["seed"]) for d in loss_logs}) == rec["seeds"]
+        summaries = [d for _, d in rec["logs"] if "n_seeds" in d]
+        # the end-of-eval all-gather reached every rank; rank 0 logs the summary of all 2 K seeds (2 evaluations)
+        assert len(summaries) == (2 if r == 0 else 0)
+        for smry in summaries:
+            assert smry["n_seeds"] == 2 * K and smry["steps_per_sec_total"] > 0 and np.isfinite(smry["mean_score_mean"])
+    assert len({ps for rec in recs for ps in rec["param_sum"]}) == 2 * K  # 2 K different runs
+    # each seed as a rank / slot of this job == that seed's solo run (same parameters to the last bit)
+    import iqlpref_amd as ia  # noqa: F401  (the solo run happens in a third child: this process keeps its GPU state)
+    env1 = {k: v for k, v in base.items() if k not in ("WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                        "IQL_DIST_BACKEND")}
+    solo_dir = tmp_path / "solo"
+    solo_dir.mkdir()
+    code = ("import sys, json, os; sys.argv = ['x', %r, '1']; sys.path.insert(0, %r); "
+            "import iqlpref_amd as ia; import tests.train_rank_child as c; "
+            "real = ia.TrainConfig; "
+            "ia.TrainConfig = lambda **kw: real(**dict(kw, seed=%d)); c.main()" % (str(solo_dir), root, 100 + 2 * K - 1))
+    p = subprocess.run([sys.executable, "-c", code], env=env1, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    solo = json.load(open(solo_dir / "rank0.json"))
+    assert solo["seeds"] == [100 + 2 * K - 1] and solo["param_sum"][0] == recs[1]["param_sum"][K - 1]

@@ -243,3 +243,26 @@ def test_custom_offline_window_closed_form():
             base += L
         got = list(zip(start.tolist(), length.tolist(), t0.tolist()))
         assert got == want
+
+
+def test_reward_model_follows_the_ranks_seed(monkeypatch):
+    """iql_eval.py:143-146 ties the reward model to the run's seed.  Rank 1 of a
+    one-seed-per-GPU launch trains config.seed + 1 and must relabel with {root}_{seed + 1}, exactly as
+    slot 1 of a two-seeds-per-GPU process does -- not with the path TrainConfig.__post_init__ derived
+    from the base seed."""
+    import torch.distributed as dist
+    import iqlpref_amd as ia
+    from iqlpref_amd import distributed as D
+    from iqlpref_amd.train import seed_configs
+    cfg = ia.TrainConfig(env="antmaze-medium-diverse-v2", seed=7, reward_model_root="/models/mr")
+    assert cfg.reward_model_path == "/models/mr_7"
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_rank", lambda: 1)
+    for K in (1, 2):
+        seeds = [D.rank_seed(cfg.seed, K) + k for k in range(K)]
+        assert seeds == [7 + K + k for k in range(K)]
+        per_seed = seed_configs(cfg, seeds)
+        assert [c.reward_model_path for c in per_seed] == [f"/models/mr_{s}" for s in seeds]
+        assert [c.seed for c in per_seed] == seeds and cfg.reward_model_path == "/models/mr_7"
+    plain = ia.TrainConfig(env="antmaze-medium-diverse-v2", seed=7, reward_model_path="/models/one")
+    assert all(c is plain for c in seed_configs(plain, [8, 9]))

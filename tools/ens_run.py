@@ -1,6 +1,7 @@
 """One (critics, batch) configuration of the step on its own (for rocprofv3 passes and A/B runs):
-    python tools/ens_run.py [E=4] [B=1024] [steps=3000]
-prints steps/s, algorithmic bytes per step (iqlhip_step_cost) and the HIP-event time of each kernel."""
+    python tools/ens_run.py [E=4] [B=1024] [steps=3000] [pen]
+prints steps/s, algorithmic bytes per step (iqlhip_step_cost) and the HIP-event time of each kernel.
+`pen`: BASELINE configs[2] instead of the antmaze shapes (S 45 / A 24, actor dropout 0.1, 5,000 rows)."""
 import ctypes as C
 import json
 import os
@@ -19,10 +20,17 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
 unroll = int(os.environ.get("ENS_UNROLL", "50"))
 dev = "cuda:0"
-buf = ia.ReplayBuffer(bench.S_DIM, bench.A_DIM, 200_000, dev)
-buf.load_d4rl_dataset(bench.synth_dataset(1, 200_000))
 lib = _lib.load()
-tr = bench.build_trainer(ia, torch, dev, 3, "bf16", n_critics=E)
+if "pen" in sys.argv[4:]:
+    S_, A_ = bench.PEN["dims"]
+    buf = ia.ReplayBuffer(S_, A_, bench.PEN["n_rows"], dev)
+    buf.load_d4rl_dataset(bench.synth_dataset_dims(1, bench.PEN["n_rows"], S_, A_))
+    tr = bench.build_trainer(ia, torch, dev, 3, "bf16", n_critics=E, dims=bench.PEN["dims"],
+                             dropout=bench.PEN["dropout"], hyper=bench.PEN["hyper"])
+else:
+    buf = ia.ReplayBuffer(bench.S_DIM, bench.A_DIM, 200_000, dev)
+    buf.load_d4rl_dataset(bench.synth_dataset(1, 200_000))
+    tr = bench.build_trainer(ia, torch, dev, 3, "bf16", n_critics=E)
 tr.train_steps(buf, min(500, n), B, return_losses=False, graph_unroll=unroll)
 torch.cuda.synchronize()
 t = time.perf_counter()

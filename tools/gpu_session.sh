@@ -113,12 +113,6 @@ print('agents', d.get('agents_per_gpu',{}).get('value'), 'ensemble', d.get('ense
         IQLHIP_LIB=$PWD/iqlpref_amd/$lib timeout -k 10 200 python tools/group_scan.py 8 2>&1 | grep -v Dataset >> $OUT/ab_${VARIANT}_group.txt; rc=$?; stop_if_killed $rc abgroup
       done; done
       cut -c1-300 $OUT/ab_${VARIANT}_group.txt ;;
-    pmcfull)
-      # ONE counter pass over bench.py's default regions (incl. the 20,000-step sustained one): the
-      # command that aborted in r2m (INVALID_PACKET_FORMAT) before the library bounded its queue depth
-      export TMPDIR=/tmp
-      timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmcfull -- python bench.py --steps 500 --warmup 100 --no-cpu-baseline --no-relabel --agents-per-gpu 0 --ensemble-q 0 --min-timed-s 0.05 > $OUT/pmcfull.json 2> $OUT/pmcfull.err
-      rc=$?; echo "pmcfull rc=$rc"; tail -c 600 $OUT/pmcfull.json; tail -5 $OUT/pmcfull.err | cut -c1-300; rm -rf $OUT/pmcfull; stop_if_killed $rc pmcfull ;;
     profile)
       bash tools/profile.sh $TAG > $OUT/profile.log 2>&1; rc=$?; echo "profile rc=$rc"; tail -5 $OUT/profile.log | cut -c1-300; [ $rc = 0 ] || exit 1 ;;
   esac

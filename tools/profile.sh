@@ -10,8 +10,10 @@ OUT=$PWD/gpurun_out/prof_$TAG
 # (--unroll 50: the traced runs replay hipGraphs of 50 steps.  bench.py's default, plain kernel launches,
 # is paced by the tracer's per-dispatch interception -- ~6 us per launch, 18.7 us per step instead of
 # 14.9 -- and the "durations" of kernels that tile the step then measure the tool, not the kernels.)
-ARGS="--unroll 50 --no-cpu-baseline --no-relabel --agents-per-gpu 0 --ensemble-q 0 --min-timed-s 0.05"
+ARGS="--unroll 50 --no-cpu-baseline --no-relabel --no-pen --agents-per-gpu 0 --ensemble-q 0 --min-timed-s 0.05"
 mkdir -p $OUT
+# which library the set was collected on (bench.py labels every profile-derived figure with it)
+python -c "from iqlpref_amd import _lib; import json; print(json.dumps({'build': _lib.build_tag(), 'tag': '$TAG'}))" > $OUT/meta.json
 export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 3000 --warmup 300 $ARGS > $OUT/trace.json
 echo "trace done"
@@ -38,6 +40,19 @@ find $OUT/group -name "*kernel_stats.csv" -exec cp {} $OUT/group8_kernel_stats.c
 GROUP_SCAN_STEPS=500 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/gfetch -- python tools/group_scan.py 8 > $OUT/gfetch.json
 GROUP_SCAN_STEPS=500 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/gwrite -- python tools/group_scan.py 8 > $OUT/gwrite.json
 echo "group pmc done"
+# BASELINE configs[4] (E = 4 critics, batch 1024) and configs[2] (pen shapes + dropout, batch 256): kernel trace
+# + stats, and the fabric traffic of the ensemble step (short regions, see above)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ens -- python tools/ens_run.py 4 1024 3000 > $OUT/ens4.json
+find $OUT/ens -name "*kernel_stats.csv" -exec cp {} $OUT/ens4_kernel_stats.csv \;
+ENS_NO_TIMING=1 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/efetch -- python tools/ens_run.py 4 1024 500 > $OUT/efetch.json
+ENS_NO_TIMING=1 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/ewrite -- python tools/ens_run.py 4 1024 500 > $OUT/ewrite.json
+python tools/pmc_summary.py $OUT/efetch 1 $OUT/ens4_pmc_fetch_size.json > /dev/null
+python tools/pmc_summary.py $OUT/ewrite 1 $OUT/ens4_pmc_write_size.json > /dev/null
+python tools/traffic_json.py $OUT/ens4_pmc_fetch_size.json $OUT/ens4_pmc_write_size.json $OUT/ens4_traffic.json
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pen -- python tools/ens_run.py 2 256 3000 pen > $OUT/pen.json
+find $OUT/pen -name "*kernel_stats.csv" -exec cp {} $OUT/pen_kernel_stats.csv \;
+rm -rf $OUT/ens $OUT/efetch $OUT/ewrite $OUT/pen
+echo "ens4 / pen done"
 python tools/pmc_summary.py $OUT/gfetch 1 $OUT/group8_pmc_fetch_size.json > /dev/null
 python tools/pmc_summary.py $OUT/gwrite 1 $OUT/group8_pmc_write_size.json > /dev/null
 python tools/traffic_json.py $OUT/group8_pmc_fetch_size.json $OUT/group8_pmc_write_size.json $OUT/group8_traffic.json
