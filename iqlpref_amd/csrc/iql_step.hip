@@ -147,12 +147,30 @@ __device__ __forceinline__ void act_store8(uint16_t *base, size_t elem, uint2 u)
 // to a feature-major plane as ONE 16-byte store per lane (permlane16_swap): the lane of row group q
 // ends up with rows 16 (m + (q & 1)) + 4 (q & ~1) .. + 7 of its column.  Same bytes at the same
 // addresses as two act_store8 calls.
+// IQL_WT_ACT16: these 16-byte stores leave write-through (sc0 sc1).  A wave's store instruction covers one
+// whole 1 KiB fragment (8 full lines), so nothing is merged in L2 anyway, and what a kernel leaves dirty
+// is written back at its END, by the L2s of the few XCDs that hold it: in-kernel stamps (round 4, four
+// critics at batch 1024) show the last forward work-group done 5.4 us after the first started and the
+// first backward work-group starting at +12.1 us -- 7 MB of activations leaving six L2s.
+// A/B on one box (round 4, d2): four critics at batch 1024 31.2k -> 35.3k steps/s, 8 seeds per launch
+// 208.7k -> 220.3k (throughput kernels), 4 seeds 156.5k -> 168.0k (k_forward<.., 2, 2>), one seed
+// unchanged (66.1k: its 16-row work-groups have no tile pairs).  -DIQL_WT_ACT16=0 builds plain stores.
+#ifndef IQL_WT_ACT16
+#define IQL_WT_ACT16 1
+#endif
+__device__ __forceinline__ void act_store16(uint16_t *plane, size_t elem, uint4 v) {
+#if IQL_WT_ACT16
+  stg16_wt(plane, (uint32_t)elem * 2u, __builtin_bit_cast(float4, v));
+#else
+  stg16(plane + elem, __builtin_bit_cast(float4, v));
+#endif
+}
 __device__ __forceinline__ void act_store16_pair(uint16_t *plane, int col, int row_m, int q, int nkb, uint2 um,
                                                  uint2 um1) {
   permlane16_swap(um.x, um1.x);
   permlane16_swap(um.y, um1.y);
   const int k0 = row_m + 16 * (q & 1) + 4 * (q & ~1);
-  stg16(plane + fidx<Prec<true>>(col, k0, nkb), __builtin_bit_cast(float4, make_uint4(um.x, um.y, um1.x, um1.y)));
+  act_store16(plane, fidx<Prec<true>>(col, k0, nkb), make_uint4(um.x, um.y, um1.x, um1.y));
 }
 
 // relu(round(acc + bias)) of the four batch rows a lane holds for one hidden unit (MFMA C layout),
@@ -1441,8 +1459,7 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
             drow[2 * HP] = (T)(u2[e].y & 0xffff), drow[3 * HP] = (T)(u2[e].y >> 16);
           }
           if (mine)
-            stg16(dst + fidx<P>(c2, slab * SLAB + 8 * h8, nkb),
-                  __builtin_bit_cast(float4, make_uint4(u2[0].x, u2[0].y, u2[1].x, u2[1].y)));
+            act_store16(dst, fidx<P>(c2, slab * SLAB + 8 * h8, nkb), make_uint4(u2[0].x, u2[0].y, u2[1].x, u2[1].y));
         }
       }
     }
@@ -1741,8 +1758,7 @@ __global__ __launch_bounds__(512, 1) void k_backward_tp(const TrainerDesc *__res
           drow[0] = (T)(u2[e].x & 0xffff), drow[HP] = (T)(u2[e].x >> 16);
           drow[2 * HP] = (T)(u2[e].y & 0xffff), drow[3 * HP] = (T)(u2[e].y >> 16);
         }
-        stg16(dst + fidx<P>(c2, slab * SLAB + 8 * h8, nkb),
-              __builtin_bit_cast(float4, make_uint4(u2[0].x, u2[0].y, u2[1].x, u2[1].y)));
+        act_store16(dst, fidx<P>(c2, slab * SLAB + 8 * h8, nkb), make_uint4(u2[0].x, u2[0].y, u2[1].x, u2[1].y));
       }
     } else {
 #pragma unroll
@@ -2035,7 +2051,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   // partials in all of it (UPD_LDS floats; host check in api.hip).
   __shared__ __attribute__((aligned(16))) float lds_upd[UPD_LDS];
   float *const tile = lds_upd, *const tile2 = lds_upd + UPD_TILE;
-  __shared__ float bgrad[UTO];
+  __shared__ float bgrad[UTO], bgrad2[UTO];  // (bgrad2: the second half of a split batch)
   STAMP(2, 0);
 
   if (blk >= n_items) {
@@ -2103,6 +2119,17 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       it.group == 0 ? coef.neg_step[0] : (it.group == 1 ? coef.neg_step[1] : coef.neg_step[2]);
   const bool has_target = it.has_target != 0;
   const int nk = BP / P::KM;
+  // Long batches (16 k-steps and more: batch >= 512 in bf16): the tile GEMMs sum the batch in TWO
+  // halves, k-steps [0, kh) and [kh, nk), each in ascending order, and add the halves (fp32) -- in the
+  // group variant two wave pairs take a half each (the whole work-group streams operands: twice the
+  // bytes in flight on a loop that is bound by load latency x depth: stamps of round 4, 32 k-steps in
+  // 5.4 us on two waves), in the one-seed variant every wave runs the halves one after the other into
+  // two accumulators.  The same sum either way: a seed in a group launch stays the seed alone.
+  // bf16 only: precision = fp32 (the parity mode, 16 k-steps already at batch 256) keeps ONE ascending
+  // sum per element -- measured there: the first 100 steps of the reference's 1,000-step trajectories
+  // agree to 6e-7 with that order and to 5e-4 with the split one (tests/test_gpu_long_horizon.py).
+  const int kh = (BF16 && nk >= 16) ? (nk / (2 * UKC)) * UKC : nk;  // (scalar; = nk: no split)
+  const bool ksplit = kh < nk;
   // descriptor / item fields of the Adam and store phases: fetched with the first batch
   pin_s(D.tau), pin_s(D.one_m_tau), pin_s(D.polyak_convex);
   pin_s(it.off_w), pin_s(it.toff_w), pin_s(it.off_b), pin_s(it.toff_b), pin_s(it.wc), pin_s(it.tc);
@@ -2357,14 +2384,15 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
         for (int b = 0; b < UNB; ++b) zf[ks][b] = ldg16(zb[b] + (size_t)kk * 1024 + lane16);
       }
     };
-    auto mma_frags = [&](const int k0, const uint4(&xf)[UKC], const uint4(&zf)[UKC][UNB]) {
+    auto mma_frags = [&](const int k0, const uint4(&xf)[UKC], const uint4(&zf)[UKC][UNB], f32x4(&ac)[UNB],
+                         float(&bs)[UNB]) {
 #pragma unroll
       for (int ks = 0; ks < UKC; ++ks) {
         if (k0 + ks < nk) {
 #pragma unroll
           for (int b = 0; b < UNB; ++b) {
-            if (wave_bias) frag_acc<BF16>(bsum[b], zf[ks][b]);  // bias gradient = row sums of dZ^T
-            P::mma(xf[ks], zf[ks][b], acc[b]);
+            if (wave_bias) frag_acc<BF16>(bs[b], zf[ks][b]);  // bias gradient = row sums of dZ^T
+            P::mma(xf[ks], zf[ks][b], ac[b]);
           }
         }
       }
@@ -2378,12 +2406,30 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     load_state();  // right behind the operand fragments: everything in flight at once
     STAMP(2, 1);
     __builtin_amdgcn_sched_barrier(0);
-    mma_frags(0, xf0, zf0);
+    mma_frags(0, xf0, zf0, acc, bsum);
 #pragma unroll 1
-    for (int k0 = UKC; k0 < nk; k0 += UKC) {
+    for (int k0 = UKC; k0 < kh; k0 += UKC) {
       uint4 xf[UKC], zf[UKC][UNB];
       load_frags(k0, xf, zf);
-      mma_frags(k0, xf, zf);
+      mma_frags(k0, xf, zf, acc, bsum);
+    }
+    if (ksplit) {  // the second half of a long batch into its own accumulators, then lo + hi
+      f32x4 acc_hi[UNB];
+      float bsum_hi[UNB];
+#pragma unroll
+      for (int b = 0; b < UNB; ++b) acc_hi[b] = f32x4{0.f, 0.f, 0.f, 0.f}, bsum_hi[b] = 0.f;
+#pragma unroll 1
+      for (int k0 = kh; k0 < nk; k0 += UKC) {
+        uint4 xf[UKC], zf[UKC][UNB];
+        load_frags(k0, xf, zf);
+        mma_frags(k0, xf, zf, acc_hi, bsum_hi);
+      }
+#pragma unroll
+      for (int b = 0; b < UNB; ++b) {
+        acc[b] += acc_hi[b];
+        if (wave_bias) bsum[b] = xor32_sum(xor16_sum(bsum[b])), bsum_hi[b] = xor32_sum(xor16_sum(bsum_hi[b]));
+        bsum[b] += bsum_hi[b];
+      }
     }
     // C/D layout: lane (r, q) of acc[b] holds dW[ob + 16 b + r][ib + 4 q + k]
 #pragma unroll
@@ -2393,7 +2439,7 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 #pragma unroll
       for (int b = 0; b < UNB; ++b) {
         float bs = bsum[b];
-        bs = xor32_sum(xor16_sum(bs));
+        if (!ksplit) bs = xor32_sum(xor16_sum(bs));  // (split: the halves were reduced before they were added)
         if (q == 0) bgrad[16 * UNB * wo + 16 * b + r] = bs;
       }
     }
@@ -2417,7 +2463,10 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 #endif
     constexpr int GW = IQL_GW, GNB = (UTO / 16) / GW, GNI = UTI / 16, GIF = IQL_GIF;
     static_assert(UT == 256 && UTO == 64 && (GW == 1 || GW == 2), "the GEMM waves cover a 64-row tile");
-    const bool gemm_wave = wave < GW;  // (scalar)
+    // (split batch: all four waves are GEMM waves -- wave pair `half` takes k-steps [half kh, ...) )
+    const bool gemm_wave = ksplit || wave < GW;  // (scalar)
+    const int gw = wave & (GW - 1), half = ksplit ? wave / GW : 0;
+    const int kbeg = half ? kh : 0, kend = ksplit ? (half ? nk : kh) : nk;
     const bool wave_bias = do_bias && gemm_wave;
     f32x4 acc[GNB][GNI];
     float bsum[GNB];
@@ -2436,30 +2485,31 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
 #endif
       STAMP(2, 1);
     } else {
+      static_assert(GW == 2 || IQL_GW == 1, "split batches pair the waves (GW = 2)");
       const char *xb[GNI], *zb[GNB];
 #pragma unroll
       for (int c = 0; c < GNI; ++c) xb[c] = reinterpret_cast<const char *>(Xsrc) + (size_t)(((i0 >> 4) + c) * nk) * 1024;
 #pragma unroll
       for (int b = 0; b < GNB; ++b) {
-        const int t_ = (o0 >> 4) + GNB * wave + b;
+        const int t_ = (o0 >> 4) + GNB * gw + b;
         zb[b] = reinterpret_cast<const char *>(Zsrc) + (size_t)((t_ < ntile_o ? t_ : ntile_o - 1) * nk) * 1024;
       }
       uint4 xf[UKC][GNI], zf[UKC][GNB];  // (a k-step's registers are live from its issue to its MFMAs only)
       auto issue = [&](const int k0, const int ks) {
-        const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
+        const int kk = k0 + ks < kend ? k0 + ks : kend - 1;
 #pragma unroll
         for (int c = 0; c < GNI; ++c) xf[ks][c] = ldg16(xb[c] + (size_t)kk * 1024 + lane16);
 #pragma unroll
         for (int b = 0; b < GNB; ++b) zf[ks][b] = ldg16(zb[b] + (size_t)kk * 1024 + lane16);
       };
-      auto chunk = [&](const int k0) {
+      auto chunk = [&](const int k0, const bool first) {
 #pragma unroll
         for (int ks = 0; ks < GIF; ++ks) issue(k0, ks);
-        if (k0 == 0) STAMP(2, 1);
+        if (first) STAMP(2, 1);
 #pragma unroll
         for (int ks = 0; ks < UKC; ++ks) {
           __builtin_amdgcn_sched_barrier(0);
-          if (k0 + ks < nk) {
+          if (k0 + ks < kend) {
 #pragma unroll
             for (int b = 0; b < GNB; ++b) {
               if (wave_bias) frag_acc<BF16>(bsum[b], zf[ks][b]);
@@ -2471,30 +2521,31 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
           if (ks + GIF < UKC) issue(k0, ks + GIF);  // into the registers the k-step just consumed freed
         }
       };
-      chunk(0);  // straight-line first chunk (a loop pre-header would drain the pending loads)
+      chunk(kbeg, true);  // straight-line first chunk (a loop pre-header would drain the pending loads)
 #pragma unroll 1
-      for (int k0 = UKC; k0 < nk; k0 += UKC) chunk(k0);
+      for (int k0 = kbeg + UKC; k0 < kend; k0 += UKC) chunk(k0, false);
       __builtin_amdgcn_sched_barrier(0);
       load_state();  // the operand registers are free now
       // C/D layout: lane (r, q) of acc[b][c] holds dW[o0 + 32 g + 16 b + r][i0 + 16 c + 4 q + k]
+      float *const tdst = half ? tile2 : tile;  // (the second half's partial sums: added in the Adam pass)
 #pragma unroll
       for (int b = 0; b < GNB; ++b)
 #pragma unroll
         for (int c = 0; c < GNI; ++c)
-          *reinterpret_cast<f32x4 *>(&tile[(16 * GNB * wave + 16 * b + r) * ULD + 16 * c + 4 * q]) = acc[b][c];
+          *reinterpret_cast<f32x4 *>(&tdst[(16 * GNB * gw + 16 * b + r) * ULD + 16 * c + 4 * q]) = acc[b][c];
       if (wave_bias) {
 #pragma unroll
         for (int b = 0; b < GNB; ++b) {
           float bs = bsum[b];
           bs = xor32_sum(xor16_sum(bs));
-          if (q == 0) bgrad[16 * GNB * wave + 16 * b + r] = bs;
+          if (q == 0) (half ? bgrad2 : bgrad)[16 * GNB * gw + 16 * b + r] = bs;
         }
       }
     }
   }
 #if !IQL_G2_EARLY
   if constexpr (!LAT) {
-    if (wave >= 2) load_state();
+    if (!ksplit && wave >= 2) load_state();
   }
 #endif
   __syncthreads();
@@ -2509,6 +2560,12 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     const int ol = tr + URPP * ps, o = o0 + ol, i = i0 + tc4;
     const float4 g4 = *reinterpret_cast<const float4 *>(&tile[ol * ULD + tc4]);
     float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    if constexpr (!LAT) {
+      if (ksplit) {  // lo + hi of a split batch (the one-seed variant added them in registers)
+        const float4 h4 = *reinterpret_cast<const float4 *>(&tile2[ol * ULD + tc4]);
+        g[0] += h4.x, g[1] += h4.y, g[2] += h4.z, g[3] += h4.w;
+      }
+    }
     float p[4] = {pw[ps][0], pw[ps][1], pw[ps][2], pw[ps][3]};
     float m[4] = {mw[ps][0], mw[ps][1], mw[ps][2], mw[ps][3]};
     float v[4] = {vw[ps][0], vw[ps][1], vw[ps][2], vw[ps][3]};
@@ -2550,7 +2607,11 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
   // ---- bias: thread t < 64 owns out-feature o0 + t ----
   if (do_bias && tid < UTO && o0 + tid < Odim) {
     const int64_t e = it.off_b + o0 + tid;
-    const float g = P::round(bgrad[tid]);
+    float gb = bgrad[tid];
+    if constexpr (!LAT) {
+      if (ksplit) gb += bgrad2[tid];
+    }
+    const float g = P::round(gb);
     adam_apply<AF>(pb, mb, vb, g, coef, neg_step);
     stg(g_params + e, pb), stg(g_m + e, mb), stg(g_v + e, vb);
     if (g_grads) stg(g_grads + e, g);
@@ -2717,7 +2778,10 @@ bool use_tp(bool bf16, const TrainerDesc &D, int n_seeds) {
   static const int forced = getenv("IQLHIP_TP") ? atoi(getenv("IQLHIP_TP")) : -1;  // A/B knob
   if (!bf16 || D.H != 256 || D.B % 64 != 0) return false;
   if (forced >= 0) return forced != 0;
-  return false;  // (round 4, first measurement: NOT faster than k_forward / k_backward -- opt-in until it is)
+  // measured (round 4, d2, write-through activation stores): four critics at batch 1024 (11,264 row-
+  // evaluations per launch) 31.6k -> 35.3k steps/s, 8 seeds at batch 256 (14,336) 200.9k -> 220.3k; 4 seeds
+  // (7,168) 168.0k -> 152.6k, one seed 66.1k -> 50.4k: the throughput kernels from ~10,000 on
+  return (int64_t)D.B * n_seeds * D.nfwd >= 10000;
 }
 // once per trainer (iqlhip_trainer_create, outside any stream capture): k_forward_tp's 64-row slabs
 // take more than the 64 KB of dynamic LDS a kernel may use by default

@@ -121,24 +121,27 @@ def test_resume_from_reference_checkpoint(gh, mode):
 
 
 # Windows of steps and the bound on the largest relative loss difference |ours / reference - 1| inside
-# each, per mode: (value_loss, q_loss, actor_loss).  Bounds = 5 x the larger of the two trajectories'
-# figures measured on an MI355X (IQL_TEST_DIAG, profiles/r04_long_horizon_diag.txt), which were
-#   fp32  steps 0-10 4.0e-7 | 10-100 6.1e-7 | 100-300 (4.7e-3, 6.9e-4, 2.6e-3) | 300-1000 (0.12, 0.031, 0.20)
-#   bf16  0-10 (6.6e-4, 1.6e-5, 3.1e-4) | 10-100 (1.2e-2, 2.1e-3, 9.4e-3) | 100-300 (0.46, 0.037, 0.22)
-#         | 300-1000 (0.40, 0.092, 0.89)
-# The numpy oracle's own drift from the same reference runs, same windows (also in that file): fp32
-# 2.5e-7 | 2.0e-4 | 9.1e-3 | (0.34, 0.088, 0.73); bf16 = this library's figures to two digits (the bf16
-# arithmetic of the two is the same, bit for bit, where no rounding tie falls the other way).  In fp32
-# this library stays CLOSER to torch than the numpy restatement does (its MFMA sums meet mkldnn's
-# order more often than numpy's BLAS does): the first 100 steps agree to 6e-7.
+# each, per mode: (value_loss, q_loss, actor_loss).  Measured on an MI355X (IQL_TEST_DIAG,
+# profiles/r04_long_horizon_diag.txt), larger of the two trajectories:
+#   this library   fp32  0-10 4.0e-7 | 10-100 6.1e-7 | 100-300 (4.7e-3, 6.9e-4, 2.6e-3) | 300-1000 (0.12, 0.031, 0.20)
+#                  bf16  0-10 (6.6e-4, 1.6e-5, 3.1e-4) | 10-100 (1.2e-2, 2.1e-3, 9.4e-3) | 100-300 (0.46, 0.037, 0.22)
+#                        | 300-1000 (0.40, 0.092, 0.89)
+#   numpy oracle   fp32  0-10 2.5e-7 | 10-100 (2.0e-4, 2.5e-5, 1.8e-5) | 100-300 (9.1e-3, 1.3e-3, 1.7e-3)
+#                        | 300-1000 (0.34, 0.088, 0.73);  bf16: this library's figures to two digits
+# Bounds = 5 x the LARGER of the two rows.  The trajectories amplify any difference in summation order:
+# a build of this library whose fp32 weight-gradient GEMM summed the batch in two halves (round 4,
+# gpurun_out/d3) drifted by 5.2e-4 over steps 10-100, like the oracle -- the 6e-7 of the shipped order is
+# a coincidence of orders (the MFMA k-order happening to meet mkldnn's), not a property to pin.  A
+# defect (a wrong bias correction, schedule or Polyak step at large t) would show at 1e-2 and more from
+# its first step on; test_resume_from_reference_checkpoint pins those without the chaos.
 WINDOWS = ((0, 10), (10, 100), (100, 300), (300, 1000))
 BOUNDS = {
-    "fp32": ((2e-6, 2e-6, 2e-6), (3e-6, 3e-6, 3e-6), (2.4e-2, 3.5e-3, 1.3e-2), (0.6, 0.15, 1.0)),
+    "fp32": ((2e-6, 2e-6, 2e-6), (1e-3, 1.3e-4, 9e-5), (4.6e-2, 6.5e-3, 1.3e-2), (1.7, 0.44, 3.7)),
     "bf16": ((3.3e-3, 8e-5, 1.5e-3), (6e-2, 1e-2, 4.7e-2), (2.3, 0.18, 1.1), (2.0, 0.46, 4.5)),
 }
 # ... and on the mean loss of a window (what train() logs, ref:1537-1544), largest of the three losses:
-# measured fp32 1.1e-7 | 2.7e-7 | 1.6e-4 | 5.6e-3, bf16 7.3e-5 | 1.9e-4 | 1.7e-2 | 1.7e-2
-MEAN_BOUNDS = {"fp32": (1e-6, 1.5e-6, 8e-4, 2.8e-2), "bf16": (4e-4, 1e-3, 9e-2, 9e-2)}
+# measured fp32 1.1e-7 | 3.2e-5 (split-order build) | 1.6e-4 | 5.6e-3, bf16 7.3e-5 | 1.9e-4 | 1.7e-2 | 1.7e-2
+MEAN_BOUNDS = {"fp32": (1e-6, 1.6e-4, 8e-4, 2.8e-2), "bf16": (4e-4, 1e-3, 9e-2, 9e-2)}
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
@@ -175,9 +178,10 @@ def test_thousand_step_trajectory_vs_reference(gh, name, mode):
         assert (got <= np.asarray(bound)).all(), (name, mode, (a, b), got, bound)
         assert (mean_rel <= mb).all(), (name, mode, (a, b), mean_rel, mb)
     # parameters after 100 and 1,000 steps: the movement from the initial weights against the reference's
-    # (strided samples).  After 100 steps the fp32 runs still move together (measured: < 5e-5 rel. L2;
-    # bf16 0.11); after 1,000 the trajectories have separated (0.16-0.29): there the movement's SIZE is
-    # compared (|norm ratio - 1| measured fp32 0.027, bf16 0.137), not its direction.
+    # (strided samples).  After 100 steps the runs still move together (measured rel. L2: fp32 < 5e-5 with
+    # the shipped summation order, the numpy oracle 0.03; bf16 0.11); after 1,000 the trajectories have
+    # separated (0.16-0.29): there the movement's SIZE is compared (|norm ratio - 1| measured fp32 0.027,
+    # bf16 0.137), not its direction.
     init = dict(zip(("qf", "vf", "actor"), nets))
     init["q_target"] = nets[0]
     final = {net: gh.module_params(mod) for net, mod in
@@ -198,5 +202,5 @@ def test_thousand_step_trajectory_vs_reference(gh, name, mode):
                 worst_n = max(worst_n, abs(float(np.linalg.norm(gd) / np.linalg.norm(wd)) - 1))
         _diag(f"{name} {mode} at {at}: movement rel L2 vs reference {worst:.4f}, |norm ratio - 1| {worst_n:.4f}")
         if at == 100:
-            assert worst < (2.5e-4 if mode == "fp32" else 0.5), (name, mode, at, worst)
+            assert worst < (0.15 if mode == "fp32" else 0.5), (name, mode, at, worst)
         assert worst_n < (0.13 if mode == "fp32" else 0.65), (name, mode, at, worst_n)
