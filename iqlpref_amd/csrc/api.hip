@@ -248,7 +248,12 @@ struct iqlhip_trainer {
   DevArgs *dargs = nullptr;
   DevCtr *dctr = nullptr;
   UpdItem *ditems = nullptr;
-  int n_items = 0;
+  int n_items = 0;      // of the table `ditems` points to (the group's while the trainer is a member of one)
+  int own_n_items = 0;  // of the trainer's own table
+  // host copy of the update kernel's work items, per trained net: first the items of the lower half of
+  // every layer, then the upper half (n_half0 of them in the first part) -- tables are dealt from these
+  std::vector<UpdItem> net_items[MAX_TRAIN];
+  int n_half0[MAX_TRAIN] = {};
   // the slots of this trainer's own workspace; ddesc / dargs / dctr / ditems point into a
   // group's contiguous arrays while the trainer is a member of one (iqlhip_group_create)
   TrainerDesc *own_ddesc = nullptr;
@@ -391,6 +396,73 @@ static T *carve(char *&p, size_t n) {
   return r;
 }
 
+// The update kernel's item table is XCD-major: block b runs on XCD b & 7 (round-robin dispatch), so
+// slot i of the table belongs to XCD i & 7, row i >> 3.  `per_xcd` lists what each XCD works on; rows
+// are padded with idle slots (net = -1), which gather the next step's batch: they are numbered
+// (o0 = index, i0 = count).  `min_depth`: tables of one group share their size.
+static std::vector<UpdItem> flatten_table(const std::vector<UpdItem> (&per_xcd)[8], size_t min_depth, size_t *depth_out) {
+  size_t depth = 0, n_real = 0;
+  for (auto &v : per_xcd) depth = v.size() > depth ? v.size() : depth, n_real += v.size();
+  // a table that happens to be (almost) full gets two more rows of slots for the batch prefetch
+  if (8 * depth - n_real < 16) depth += 2;
+  if (depth < min_depth) depth = min_depth;
+  std::vector<UpdItem> items;
+  for (size_t d = 0; d < depth; ++d)
+    for (int x = 0; x < 8; ++x) {
+      UpdItem pad;
+      memset(&pad, 0, sizeof(pad));
+      pad.net = -1;
+      items.push_back(d < per_xcd[x].size() ? per_xcd[x][d] : pad);
+    }
+  int n_pad = 0;
+  for (auto &it : items)
+    if (it.net < 0) it.o0 = n_pad++;
+  for (auto &it : items)
+    if (it.net < 0) it.i0 = n_pad;
+  if (depth_out) *depth_out = depth;
+  return items;
+}
+
+// Which XCD works on which items.
+//   one seed per launch, TwinQ (4 trained nets): network n on XCDs 2n and 2n + 1, each taking half of
+//     every layer (the panels a GEMM shares meet in two L2s, the bytes are spread over all eight);
+//   one seed, more critics: the nets' items dealt out in order, an eighth of all items per XCD (6 nets
+//     on pairs of XCDs left four XCDs with twice the work: E = 4 at batch 1024, round 4);
+//   member k of a group launch: a WHOLE network per XCD -- (2n + k) & 7 for four nets: the eight
+//     members of a group put one network of every kind on every XCD -- so that its activation / delta
+//     panels are fetched from memory into ONE L2 (the balanced one-seed table fetches them into two:
+//     2.9 MB of the 13.1 MB a seed's update moved in round 3).
+// Measured (round 4, gpurun_out/e1, steps/s with the one-seed table / the whole-network table in every
+// member): 8 seeds 219.7k / 223.6k (k_update 17.3 -> 16.7 us), 4 seeds 167.7k / 160.0k, 2 seeds 111.4k /
+// 107.7k -- the rotation gives every XCD one network of every kind only for multiples of eight members;
+// smaller groups keep the one-seed table.  Dealt in order (E > 2, one seed): E = 4 at batch 1024 35.9k ->
+// 37.5k steps/s, E = 8 at batch 256 41.0k -> 42.4k.
+static void deal_items(const iqlhip_trainer *t, int member, int group_size, std::vector<UpdItem> (&per_xcd)[8]) {
+  const int NT = t->D.ntrain;
+  static const int forced = getenv("IQLHIP_ITEM_TABLE") ? atoi(getenv("IQLHIP_ITEM_TABLE")) : -1;  // A/B: 0 / 1 forces
+  const bool group = group_size > 1;
+  const bool whole = forced >= 0 ? (forced != 0 && group) : (group && group_size % 8 == 0);
+  if (whole && NT == 4) {
+    for (int n = 0; n < NT; ++n)
+      for (auto &it : t->net_items[n]) per_xcd[(2 * n + member) & 7].push_back(it);
+    return;
+  }
+  if (NT == 4) {
+    for (int n = 0; n < NT; ++n)
+      for (size_t i = 0; i < t->net_items[n].size(); ++i)
+        per_xcd[(2 * n + ((int)i < t->n_half0[n] ? 0 : 1)) & 7].push_back(t->net_items[n][i]);
+    return;
+  }
+  size_t total = 0, g = 0;
+  for (int n = 0; n < NT; ++n) total += t->net_items[n].size();
+  for (int n = 0; n < NT; ++n)
+    for (auto &it : t->net_items[n]) {
+      const int x = (int)(g * 8 / total);
+      per_xcd[(x + (group ? member : 0)) & 7].push_back(it);
+      ++g;
+    }
+}
+
 extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_config *cfg,
                                      const iqlhip_arenas *ar) {
   if (!out) return fail(IQLHIP_ERR_INVALID, "null out");
@@ -476,59 +548,34 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   add(sizeof(DevArgs));
   add(sizeof(DevCtr));
   add(sizeof(TrainerDesc));
-  // update work items
-  // Work items of the update kernel, laid out XCD-major: block b runs on XCD b & 7
-  // (round-robin dispatch), network n's tiles go to XCDs 2n and 2n+1 so that the
-  // dZ^T / activation panels they share are fetched into those two L2s only.
-  // (pointers are filled in after the workspace has been carved)
-  std::vector<UpdItem> per_xcd[8];
+  // update work items (see deal_items / flatten_table): per net, the lower half of every layer first
   for (int n = 0; n < NT; ++n) {
-    // Both XCDs of a network take half of EVERY layer's work (the upper / the lower half of the
-    // out-features; a one-tile-row output layer by in-feature tile parity).  The layer-2 tiles carry
-    // 87 % of the optimiser state: with all of them on the even XCDs (rounds 1-2: one L2 per GEMM's
-    // panels) four of the eight XCDs moved nearly all bytes of a launch -- no matter for one seed
-    // (65.8k steps/s either way), but 8 seeds per launch 190.0k -> 201.1k, 4 seeds 144.5k -> 154.3k
-    // (k_update 19.8 -> 17.6 us; IQLHIP_ITEM_BALANCE=0 builds the old table).  Moving an eighth of
-    // the critics' tiles (which also carry the targets) to the other networks' XCDs: +0.5 %, not taken.
-    static const bool balance = !(getenv("IQLHIP_ITEM_BALANCE") && atoi(getenv("IQLHIP_ITEM_BALANCE")) == 0);
+    std::vector<UpdItem> half[2];
     auto put = [&](int layer, int o0, int i0) {
       UpdItem it;
       memset(&it, 0, sizeof(it));
       it.net = n, it.layer = layer, it.o0 = o0, it.i0 = i0;
-      int x = 2 * n + (layer == 1 ? 0 : 1);
-      if (balance) {
-        const int rows = layer == 2 ? outpad[n] : H;
-        x = 2 * n + ((layer == 2 && rows <= 64) ? ((i0 / 32) & 1) : (o0 >= rows / 2 ? 1 : 0));
-      }
-      per_xcd[x & 7].push_back(it);
+      const int rows = layer == 2 ? outpad[n] : H;
+      half[(layer == 2 && rows <= 64) ? ((i0 / 32) & 1) : (o0 >= rows / 2 ? 1 : 0)].push_back(it);
     };
     for (int o0 = 0; o0 < H; o0 += 64)
       for (int i0 = 0; i0 < H; i0 += 32) put(1, o0, i0);
     for (int o0 = 0; o0 < H; o0 += strip_rows()) put(0, o0, 0);  // layer 1: strips over all in-features
     for (int o0 = 0; o0 < outpad[n]; o0 += 64)
       for (int i0 = 0; i0 < H; i0 += 32) put(2, o0, i0);
+    t->n_half0[n] = (int)half[0].size();
+    t->net_items[n] = half[0];
+    t->net_items[n].insert(t->net_items[n].end(), half[1].begin(), half[1].end());
   }
-  size_t depth = 0, n_real = 0;
-  for (auto &v : per_xcd) depth = v.size() > depth ? v.size() : depth, n_real += v.size();
-  // the slots the table's padding leaves idle gather the next step's batch (k_update); a table
-  // that happens to be full gets two more rows of slots for that
-  if (8 * depth - n_real < 16) depth += 2;
-  std::vector<UpdItem> items;
-  for (size_t d = 0; d < depth; ++d)
-    for (int x = 0; x < 8; ++x) {
-      UpdItem pad;
-      memset(&pad, 0, sizeof(pad));
-      pad.net = -1;
-      items.push_back(d < per_xcd[x].size() ? per_xcd[x][d] : pad);
-    }
-  // the padding slots prefetch the next step's batch: number them
-  int n_pad = 0;
-  for (auto &it : items)
-    if (it.net < 0) it.o0 = n_pad++;
-  for (auto &it : items)
-    if (it.net < 0) it.i0 = n_pad;
-  t->n_items = (int)items.size();
-  add(items.size() * sizeof(UpdItem));
+  size_t n_slots;
+  {
+    std::vector<UpdItem> per_xcd[8];
+    deal_items(t, 0, 1, per_xcd);  // (sizes only: D.ntrain is set, the pointers are filled in below)
+    size_t depth = 0;
+    n_slots = flatten_table(per_xcd, 0, &depth).size();
+  }
+  t->n_items = t->own_n_items = (int)n_slots;
+  add(n_slots * sizeof(UpdItem));
 
   if (hipMalloc(&t->ws, total) != hipSuccess) {
     delete t;
@@ -579,14 +626,14 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   D.next_off = iqlhip_replay_next_offset(S, A);
   // the idle slots of the update kernel gather the next step's batch; without them (or with
   // IQLHIP_NO_PREFETCH, the A/B of tests/test_gpu_step.py) k_stage runs before every step
-  D.prefetch = (n_pad > 0 && !getenv("IQLHIP_NO_PREFETCH")) ? 1 : 0;
+  D.prefetch = !getenv("IQLHIP_NO_PREFETCH") ? 1 : 0;  // (every table has idle slots: flatten_table)
   t->own_dargs = t->dargs = carve<DevArgs>(p, 1);
   t->own_dctr = t->dctr = carve<DevCtr>(p, 1);
   t->own_ddesc = t->ddesc = carve<TrainerDesc>(p, 1);
-  t->own_ditems = t->ditems = carve<UpdItem>(p, items.size());
+  t->own_ditems = t->ditems = carve<UpdItem>(p, n_slots);
 
-  for (auto &it : items) {
-    if (it.net < 0) continue;
+  for (int n_ = 0; n_ < NT; ++n_)
+  for (auto &it : t->net_items[n_]) {
     const TrainNet &N = D.net[it.net];
     const int L = it.layer;
     it.Odim = (L == 2) ? N.out_dim : H;
@@ -605,7 +652,13 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
               : (L == 1) ? reinterpret_cast<char *>(D.dz2T) + (size_t)it.net * plane
                          : reinterpret_cast<char *>(D.dz3T) + (size_t)it.net * D.opmax * D.BP * es;
   }
-  if (hipMemcpy(t->ditems, items.data(), items.size() * sizeof(UpdItem), hipMemcpyHostToDevice) !=
+  std::vector<UpdItem> items;
+  {
+    std::vector<UpdItem> per_xcd[8];
+    deal_items(t, 0, 1, per_xcd);
+    items = flatten_table(per_xcd, 0, nullptr);
+  }
+  if (items.size() != n_slots || hipMemcpy(t->ditems, items.data(), items.size() * sizeof(UpdItem), hipMemcpyHostToDevice) !=
       hipSuccess) {
     (void)hipFree(t->ws);
     delete t;
@@ -882,6 +935,7 @@ extern "C" int iqlhip_train_batch(iqlhip_trainer *t, const float *s, const float
 // agents per GPU for the same reason, ensemble_sweeps/launch.sh:12 AGENTS_PER_GPU).
 struct iqlhip_group {
   int K = 0;
+  int n_items = 0;  // slots of every member's item table (deal_items: a whole network per XCD, rotated by member)
   iqlhip_trainer *tr[IQLHIP_MAX_GROUP] = {};
   void *mem = nullptr;  // [K] TrainerDesc | [K] DevArgs | [K] DevCtr | [K][n_items] UpdItem
   TrainerDesc *gdesc = nullptr;
@@ -929,7 +983,26 @@ extern "C" int iqlhip_group_create(iqlhip_group **out, iqlhip_trainer *const *tr
   iqlhip_group *g = new (std::nothrow) iqlhip_group();
   if (!g) return fail(IQLHIP_ERR_NOMEM, "host allocation failed");
   g->K = n;
-  const int ni = trainers[0]->n_items;
+  // the members' item tables, dealt for a group launch; one size for all
+  std::vector<std::vector<UpdItem>> tables(n);
+  {
+    size_t depth = 0;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int k = 0; k < n; ++k) {
+        std::vector<UpdItem> per_xcd[8];
+        deal_items(trainers[k], k, n, per_xcd);
+        size_t d = 0;
+        tables[k] = flatten_table(per_xcd, depth, &d);
+        depth = d > depth ? d : depth;
+      }
+  }
+  const int ni = (int)tables[0].size();
+  for (int k = 0; k < n; ++k)
+    if ((int)tables[k].size() != ni) {
+      delete g;
+      return fail(IQLHIP_ERR_INVALID, "item tables of the members differ in size");
+    }
+  g->n_items = ni;
   auto up = [](size_t b) { return (b + 255) / 256 * 256; };
   const size_t b_desc = up(sizeof(TrainerDesc) * n), b_args = up(sizeof(DevArgs) * n),
                b_ctr = up(sizeof(DevCtr) * n), b_items = up(sizeof(UpdItem) * (size_t)ni * n);
@@ -950,7 +1023,7 @@ extern "C" int iqlhip_group_create(iqlhip_group **out, iqlhip_trainer *const *tr
     if (e == hipSuccess) e = hipMemcpy(g->gargs + k, t->dargs, sizeof(DevArgs), hipMemcpyDeviceToDevice);
     if (e == hipSuccess) e = hipMemcpy(g->gctr + k, t->dctr, sizeof(DevCtr), hipMemcpyDeviceToDevice);
     if (e == hipSuccess)
-      e = hipMemcpy(g->gitems + (size_t)k * ni, t->ditems, sizeof(UpdItem) * ni, hipMemcpyDeviceToDevice);
+      e = hipMemcpy(g->gitems + (size_t)k * ni, tables[k].data(), sizeof(UpdItem) * ni, hipMemcpyHostToDevice);
   }
   if (e != hipSuccess) {
     (void)hipFree(g->mem);
@@ -962,6 +1035,7 @@ extern "C" int iqlhip_group_create(iqlhip_group **out, iqlhip_trainer *const *tr
     g->tr[k] = t;
     t->group = g;
     t->ddesc = g->gdesc + k, t->dargs = g->gargs + k, t->dctr = g->gctr + k, t->ditems = g->gitems + (size_t)k * ni;
+    t->n_items = ni;
     // the member's DevArgs slot has moved: its next solo call must send its arguments and stage
     // its first batch again (`continues` would otherwise trust what the OLD slot held)
     t->dev_args_valid = false;
@@ -983,6 +1057,7 @@ extern "C" int iqlhip_group_destroy(iqlhip_group *g) {
     iqlhip_trainer *t = g->tr[k];
     (void)hipMemcpy(t->own_dctr, t->dctr, sizeof(DevCtr), hipMemcpyDeviceToDevice);
     t->ddesc = t->own_ddesc, t->dargs = t->own_dargs, t->dctr = t->own_dctr, t->ditems = t->own_ditems;
+    t->n_items = t->own_n_items;
     t->group = nullptr;
     // own_dargs holds whatever the member's last solo call OUTSIDE the group sent (all zero if
     // there was none: rows = NULL): a solo call after the group must never continue from it
@@ -1010,7 +1085,7 @@ static int group_enqueue_step(iqlhip_group *g, hipStream_t st) {
   if (!t0->D.prefetch) HIP_TRY(launch_stage(t0->bf16, t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
   HIP_TRY(launch_forward(t0->bf16, t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
   HIP_TRY(launch_backward(t0->bf16, t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
-  HIP_TRY(launch_update(t0->bf16, g->gdesc, g->gargs, g->gctr, g->gitems, t0->n_items, g->K, st));
+  HIP_TRY(launch_update(t0->bf16, g->gdesc, g->gargs, g->gctr, g->gitems, g->n_items, g->K, st));
   return 0;
 }
 
@@ -1080,7 +1155,7 @@ extern "C" int iqlhip_group_train_steps(iqlhip_group *g, const iqlhip_replay_vie
       HIP_TRY(hipEventRecord(g->ev[1], st));
       HIP_TRY(launch_backward(t0->bf16, t0->D, g->gdesc, g->gargs, g->gctr, g->K, st));
       HIP_TRY(hipEventRecord(g->ev[2], st));
-      HIP_TRY(launch_update(t0->bf16, g->gdesc, g->gargs, g->gctr, g->gitems, t0->n_items, g->K, st));
+      HIP_TRY(launch_update(t0->bf16, g->gdesc, g->gargs, g->gctr, g->gitems, g->n_items, g->K, st));
       HIP_TRY(hipEventRecord(g->ev[3], st));
       HIP_TRY(hipEventRecord(g->ev[4], st));
       HIP_TRY(hipEventSynchronize(g->ev[4]));
