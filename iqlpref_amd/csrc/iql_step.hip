@@ -1653,16 +1653,26 @@ __global__ __launch_bounds__(512, 1) void k_backward_tp(const TrainerDesc *__res
   const int tile0 = wave * TPW;
   uint4 w2t[TPW][K::NK2];
   float h1v[TPW][2][4];
+  // IQL_BTP_LATE: where the 128 KB of W2^T enter the vector-memory queue -- 0: up front, behind the
+  // loss inputs (the waves stall issuing them and reach the loss phase's barriers late); 1: behind the
+  // finished forward outputs; 2: behind the loss terms.  A/B on one box (round 4, e5; steps/s for four
+  // critics at batch 1024 / 8 seeds per launch): 37.6k / 224.4k, 37.8k / 226.4k, 37.7k / 226.4k.
+#ifndef IQL_BTP_LATE
+#define IQL_BTP_LATE 1
+#endif
+  auto load_gemm_operands = [&]() {
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    const T *W2Tw = reinterpret_cast<const T *>(p_w2ct) + (size_t)(tile0 + t) * K::NK2 * 64 * P::EPV;
+    for (int t = 0; t < TPW; ++t) {
+      const T *W2Tw = reinterpret_cast<const T *>(p_w2ct) + (size_t)(tile0 + t) * K::NK2 * 64 * P::EPV;
 #pragma unroll
-    for (int ks = 0; ks < K::NK2; ++ks) w2t[t][ks] = ldg16(W2Tw + ks * 64 * P::EPV + lane * P::EPV);
+      for (int ks = 0; ks < K::NK2; ++ks) w2t[t][ks] = ldg16(W2Tw + ks * 64 * P::EPV + lane * P::EPV);
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-      load4T<BF16>(g_hT + (size_t)(net * 2 + 0) * H * BP +
-                       fidx<P>(16 * (tile0 + t) + r, (slab32 * 2 + m) * SLAB + 4 * q, nkb), h1v[t][m]);
-  }
+      for (int m = 0; m < 2; ++m)
+        load4T<BF16>(g_hT + (size_t)(net * 2 + 0) * H * BP +
+                         fidx<P>(16 * (tile0 + t) + r, (slab32 * 2 + m) * SLAB + 4 * q, nkb), h1v[t][m]);
+    }
+  };
+  if (IQL_BTP_LATE == 0) load_gemm_operands();
   STAMP(1, 1);
 
   // ---- finish the forward outputs of this slab (sum of the parts, rounding, tanh) ----
@@ -1676,6 +1686,11 @@ __global__ __launch_bounds__(512, 1) void k_backward_tp(const TrainerDesc *__res
       const float v = P::round(sum);
       fin[lrow * FIN_LD + col] = (col >= out_mean && col < out_mean + n_act) ? P::round(tanhf(v)) : v;
     }
+  }
+  if (IQL_BTP_LATE == 1) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_gemm_operands();
+    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
 
@@ -1698,6 +1713,11 @@ __global__ __launch_bounds__(512, 1) void k_backward_tp(const TrainerDesc *__res
         if (j < out_dim) dz3[j * SLAB + lrow] = d3, lterm[j * SLAB + lrow] = lt, gstd[j * SLAB + lrow] = gs;
       }
     }
+  }
+  if (IQL_BTP_LATE == 2) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_gemm_operands();
+    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
   STAMP(1, 2);
@@ -2147,19 +2167,40 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     const int64_t fbase = it.off_w + (int64_t)o0 * Idim, tbase = it.toff_w + (int64_t)o0 * Idim;
     // one ELEMENT of the flat range per thread and pass (UNE passes cover 16 x 128 elements):
     // the strip's Adam work is spread over all 512 threads instead of a quarter of them
-    constexpr int UNE = (USR * UMAXI + UT - 1) / UT;
-    const int n_el = USR * Idim;
+    // Group variant: FOUR consecutive elements per thread and pass -- a strip's flat range starts on a
+    // 16-byte boundary and is a multiple of 16 bytes long (16 rows x Idim floats; tensors start on 128-byte
+    // lines) -- so its state moves as 16-byte loads and write-through stores like a tile's, a quarter
+    // of the memory instructions (stamps of round 4, 8 seeds per launch: a strip work-group took 6.5 us,
+    // a 64 x 32 tile with 3.5 x its bytes 5.3).
+    constexpr int UNE = LAT ? (USR * UMAXI + UT - 1) / UT : 1;
+    constexpr int UN4 = LAT ? 1 : (USR * UMAXI / 4 + UT - 1) / UT;
+    const int n_el = USR * Idim, n4 = n_el >> 2;
     float pf[UNE], mf[UNE], vf[UNE], tf[UNE];
+    float4 pf4[UN4], mf4[UN4], vf4[UN4], tf4[UN4];
     float pb, mb, vb, tb;  // branch-free (see the tiles below)
     auto load_state = [&]() {
+      if constexpr (LAT) {
 #pragma unroll
-      for (int k = 0; k < UNE; ++k) {
-        const int e = tid + UT * k;
-        const int ec = e < n_el ? e : n_el - 1;  // branch-free: lanes past the end re-read the last element
-        pf[k] = ldg(g_params + fbase + ec);
-        mf[k] = ldg(g_m + fbase + ec);
-        vf[k] = ldg(g_v + fbase + ec);
-        tf[k] = ldg((has_target ? g_target + tbase : g_params + fbase) + ec);
+        for (int k = 0; k < UNE; ++k) {
+          const int e = tid + UT * k;
+          const int ec = e < n_el ? e : n_el - 1;  // branch-free: lanes past the end re-read the last element
+          pf[k] = ldg(g_params + fbase + ec);
+          mf[k] = ldg(g_m + fbase + ec);
+          vf[k] = ldg(g_v + fbase + ec);
+          tf[k] = ldg((has_target ? g_target + tbase : g_params + fbase) + ec);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < UN4; ++k) {
+          if (UT * k < n4) {  // (scalar: a pass no lane needs issues nothing)
+            const int e4 = tid + UT * k;
+            const int ec = 4 * (e4 < n4 ? e4 : n4 - 1);
+            pf4[k] = __builtin_bit_cast(float4, ldg16(g_params + fbase + ec));
+            mf4[k] = __builtin_bit_cast(float4, ldg16(g_m + fbase + ec));
+            vf4[k] = __builtin_bit_cast(float4, ldg16(g_v + fbase + ec));
+            tf4[k] = __builtin_bit_cast(float4, ldg16((has_target ? g_target + tbase : g_params + fbase) + ec));
+          }
+        }
       }
       const int ob_ = o0 + (tid & (USR - 1));  // < Odim = H always
       const int64_t eb = it.off_b + ob_;
@@ -2192,11 +2233,15 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
       }
 #pragma unroll
       for (int tb = 0; tb < TB; ++tb) {
-        const int tt = th + UWPO * tb < nit ? th + UWPO * tb : nit - 1;
+        // (the group variant skips in-feature tiles that do not exist -- S + A <= 64: every second one --
+        // with a scalar branch: 8 KB of fragments per wave through an already full vector-memory queue)
+        if (LAT || tb == 0 || th + UWPO * tb < nit) {
+          const int tt = th + UWPO * tb < nit ? th + UWPO * tb : nit - 1;
 #pragma unroll
-        for (int ks = 0; ks < UKC; ++ks) {
-          const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
-          xf[tb][ks] = ldg16(Xsrc + frag_off<P>(tt, kk, nk, lane));
+          for (int ks = 0; ks < UKC; ++ks) {
+            const int kk = k0 + ks < nk ? k0 + ks : nk - 1;
+            xf[tb][ks] = ldg16(Xsrc + frag_off<P>(tt, kk, nk, lane));
+          }
         }
       }
       if (th == 0) {
@@ -2263,21 +2308,50 @@ __device__ __forceinline__ void update_body(const TrainerDesc *__restrict__ Dp,
     const int nkw = Kw / P::KM;
     // Adam + Polyak on the flat range; the new weights (and targets) go back to LDS in
     // [row][in-feature] order for the compute copies
+    if constexpr (LAT) {
 #pragma unroll
-    for (int k = 0; k < UNE; ++k) {
-      const int e = tid + UT * k;
-      if (e < n_el) {
-        const int ol = e / Idim, i = e - ol * Idim;
-        const float g = P::round(tile[ol * TLD + i]);
-        float p_ = pf[k], m_ = mf[k], v_ = vf[k];
-        adam_apply<AF>(p_, m_, v_, g, coef, neg_step);
-        tile[ol * TLD + i] = p_;
-        state_store1(g_params, fbase + e, p_), state_store1(g_m, fbase + e, m_), state_store1(g_v, fbase + e, v_);
-        if (g_grads) stg(g_grads + fbase + e, g);
-        if (has_target) {
-          const float t_ = polyak(D, tf[k], p_);
-          tile2[ol * TLD + i] = t_;
-          state_store1(g_target, tbase + e, t_);
+      for (int k = 0; k < UNE; ++k) {
+        const int e = tid + UT * k;
+        if (e < n_el) {
+          const int ol = e / Idim, i = e - ol * Idim;
+          const float g = P::round(tile[ol * TLD + i]);
+          float p_ = pf[k], m_ = mf[k], v_ = vf[k];
+          adam_apply<AF>(p_, m_, v_, g, coef, neg_step);
+          tile[ol * TLD + i] = p_;
+          state_store1(g_params, fbase + e, p_), state_store1(g_m, fbase + e, m_), state_store1(g_v, fbase + e, v_);
+          if (g_grads) stg(g_grads + fbase + e, g);
+          if (has_target) {
+            const float t_ = polyak(D, tf[k], p_);
+            tile2[ol * TLD + i] = t_;
+            state_store1(g_target, tbase + e, t_);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < UN4; ++k) {
+        const int e4 = tid + UT * k;
+        if (UT * k < n4 && e4 < n4) {
+          float p_[4] = {pf4[k].x, pf4[k].y, pf4[k].z, pf4[k].w}, m_[4] = {mf4[k].x, mf4[k].y, mf4[k].z, mf4[k].w};
+          float v_[4] = {vf4[k].x, vf4[k].y, vf4[k].z, vf4[k].w}, t_[4] = {tf4[k].x, tf4[k].y, tf4[k].z, tf4[k].w};
+          float g_[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = 4 * e4 + j;
+            const int ol = e / Idim, i = e - ol * Idim;
+            g_[j] = P::round(tile[ol * TLD + i]);
+            adam_apply<AF>(p_[j], m_[j], v_[j], g_[j], coef, neg_step);
+            tile[ol * TLD + i] = p_[j];
+            if (has_target) {
+              t_[j] = polyak(D, t_[j], p_[j]);
+              tile2[ol * TLD + i] = t_[j];
+            }
+          }
+          state_store(g_params, fbase + 4 * e4, make_float4(p_[0], p_[1], p_[2], p_[3]));
+          state_store(g_m, fbase + 4 * e4, make_float4(m_[0], m_[1], m_[2], m_[3]));
+          state_store(g_v, fbase + 4 * e4, make_float4(v_[0], v_[1], v_[2], v_[3]));
+          if (g_grads) stg16(g_grads + fbase + 4 * e4, make_float4(g_[0], g_[1], g_[2], g_[3]));
+          if (has_target) state_store(g_target, tbase + 4 * e4, make_float4(t_[0], t_[1], t_[2], t_[3]));
         }
       }
     }
@@ -2774,9 +2848,11 @@ int fwd_parts_per_wg(int B, int H, int n_seeds) {
 
 // Launches with many rows (seed groups, batch-1024 ensembles) take the throughput kernels
 // k_forward_tp / k_backward_tp (bf16, H = 256, batch a multiple of 64); IQLHIP_TP=0 / 1 forces the choice.
-bool use_tp(bool bf16, const TrainerDesc &D, int n_seeds) {
-  static const int forced = getenv("IQLHIP_TP") ? atoi(getenv("IQLHIP_TP")) : -1;  // A/B knob
+bool use_tp(bool bf16, const TrainerDesc &D, int n_seeds, bool backward) {
+  static const int forced = getenv("IQLHIP_TP") ? atoi(getenv("IQLHIP_TP")) : -1;          // A/B knobs: both kernels,
+  static const int forced_b = getenv("IQLHIP_TP_BWD") ? atoi(getenv("IQLHIP_TP_BWD")) : -1;  // the backward alone
   if (!bf16 || D.H != 256 || D.B % 64 != 0) return false;
+  if (backward && forced_b >= 0) return forced_b != 0;
   if (forced >= 0) return forced != 0;
   // measured (round 4, d2, write-through activation stores): four critics at batch 1024 (11,264 row-
   // evaluations per launch) 31.6k -> 35.3k steps/s, 8 seeds at batch 256 (14,336) 200.9k -> 220.3k; 4 seeds
@@ -2797,7 +2873,7 @@ size_t bwd_smem_bytes(bool bf16, int H);
 
 hipError_t launch_forward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
                           const DevCtr *c, int n_seeds, hipStream_t st) {
-  if (use_tp(bf16, D, n_seeds)) {
+  if (use_tp(bf16, D, n_seeds, false)) {
     const int nsl64 = D.B / 64;
     const int grid = 8 * ((D.nfwd + 1 + 7) / 8) * nsl64;
     // (more than 64 KB of dynamic LDS: allowed by prepare_step_kernels, at trainer creation)
@@ -2848,7 +2924,7 @@ int bwd_parts_per_wg(int B, int H, int n_seeds) {
 }
 hipError_t launch_backward(bool bf16, const TrainerDesc &D, const TrainerDesc *dD, const DevArgs *a,
                            DevCtr *c, int n_seeds, hipStream_t st) {
-  if (use_tp(bf16, D, n_seeds)) {
+  if (use_tp(bf16, D, n_seeds, true)) {
     const int nslab32 = D.B / 32;
     const int nxn = (D.ntrain <= 4 && nslab32 % 2 == 0) ? 2 : 1;  // XCDs per trained net
     const int grid = 8 * ((D.ntrain * nxn + 7) / 8) * (nslab32 / nxn);
