@@ -173,6 +173,18 @@ __device__ __forceinline__ void act_store16_pair(uint16_t *plane, int col, int r
   act_store16(plane, fidx<Prec<true>>(col, k0, nkb), make_uint4(um.x, um.y, um1.x, um1.y));
 }
 
+// The forward's partial output planes (4-byte stores into a few columns of 64- to 80-byte rows: partial
+// lines).  Written through by the throughput kernel only -- A/B on one box (round 4, f4; all launches
+// write-through against none): 8 seeds per launch 225.4k -> 229.1k steps/s, 4 seeds +0.4 %, four critics
+// at batch 1024 equal, ONE seed 66.2k -> 64.4k.
+template <bool WT>
+__device__ __forceinline__ void outs_store(float *plane, size_t elem, float v) {
+  if constexpr (WT)
+    stg4_wt(plane, (uint32_t)elem * 4u, v);
+  else
+    stg(plane + elem, v);
+}
+
 // relu(round(acc + bias)) of the four batch rows a lane holds for one hidden unit (MFMA C layout),
 // in the compute type.  bf16: relu before the rounding (the same value: rounding is monotone and
 // keeps zero), two values per v_cvt_pk_bf16_f32, no round trip through f32 -- a third of the
@@ -821,7 +833,7 @@ __global__ __launch_bounds__(256, PRE ? 1 : (MT >= 4 ? 2 : 3)) void k_forward(co
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = slab * ROWS + 16 * m + 4 * q + i;
-          if (row < B) stg(outp + (size_t)row * OUTW + N.out_col + col, acc3[jt][i] + bias);
+          if (row < B) outs_store<false>(outp, (size_t)row * OUTW + N.out_col + col, acc3[jt][i] + bias);
         }
       }
     }
@@ -1116,7 +1128,7 @@ __global__ __launch_bounds__(512, 1) void k_forward_tp(const TrainerDesc *__rest
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int row = slab * ROWS + 16 * m + 4 * q + i;
-            if (row < B) stg(outp + (size_t)row * OUTW + N.out_col + col, acc3[jt][i] + bias);
+            if (row < B) outs_store<true>(outp, (size_t)row * OUTW + N.out_col + col, acc3[jt][i] + bias);
           }
         }
       }
