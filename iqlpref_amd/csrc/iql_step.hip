@@ -142,6 +142,19 @@ __device__ __forceinline__ void act_store8(uint16_t *base, size_t elem, uint2 u)
   stg8(base + elem, u);
 #endif
 }
+// IQL_WT_FWD8: the forward's 8-byte hidden-activation stores (16-row work-groups) write-through -- the
+// forward's, not the backward's (IQL_WT_ACT covers both: no gain).  A/B on one box
+// (round 4, f5, three rounds): one seed 66.1k -> 67.0k steps/s, two seeds equal.
+#ifndef IQL_WT_FWD8
+#define IQL_WT_FWD8 1
+#endif
+__device__ __forceinline__ void act_store8_fwd(uint16_t *base, size_t elem, uint2 u) {
+#if IQL_WT_FWD8
+  stg8_wt(base, (uint32_t)elem * 2u, u);
+#else
+  act_store8(base, elem, u);
+#endif
+}
 
 // The packed bf16 C-layout registers of two row tiles m (even) and m + 1 of one feature column, stored
 // to a feature-major plane as ONE 16-byte store per lane (permlane16_swap): the lane of row group q
@@ -698,7 +711,7 @@ __global__ __launch_bounds__(256, PRE ? 1 : (MT >= 4 ? 2 : 3)) void k_forward(co
           } else {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
-              if (mine && slab * ROWS + 16 * m < B) act_store8(plane, fidx<P>(col, slab * ROWS + 16 * m + 4 * q, BP / P::KM), u[m]);
+              if (mine && slab * ROWS + 16 * m < B) act_store8_fwd(plane, fidx<P>(col, slab * ROWS + 16 * m + 4 * q, BP / P::KM), u[m]);
           }
         }
         continue;
@@ -774,7 +787,7 @@ __global__ __launch_bounds__(256, PRE ? 1 : (MT >= 4 ? 2 : 3)) void k_forward(co
 #pragma unroll
             for (int m = 0; m < MT; ++m)
               if (N.train_slot >= 0 && slab * ROWS + 16 * m < B)
-                act_store8(plane, fidx<P>(col, slab * ROWS + 16 * m + 4 * q, BP / P::KM), u[m]);
+                act_store8_fwd(plane, fidx<P>(col, slab * ROWS + 16 * m + 4 * q, BP / P::KM), u[m]);
           }
         }
         continue;
