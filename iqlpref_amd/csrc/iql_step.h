@@ -8,7 +8,7 @@ namespace iqlhip {
 // trained; one step evaluates the E critics, V(s), the actor, the E target critics and V(s').
 //   trained nets : critic e = e, V = E, actor = E + 1                      (E + 2)
 //   evaluations  : q_e = e, v = E, actor = E + 1, qt_e = E + 2 + e, next_v = 2E + 2   (2E + 3)
-//   columns of the per-row forward outputs outs[B][OUTW]:
+//   columns of the forward outputs (planes outs[part][column][row]):
 //                  q_e = e, v = E, qt_e = E + 1 + e, next_v = 2E + 1, mean_j = 2E + 2 + j
 constexpr int MAX_CRITICS = 8;
 constexpr int MAX_TRAIN = MAX_CRITICS + 2;
@@ -69,8 +69,9 @@ struct TrainerDesc {
   void *dz1T;     // [ntrain][H][B]
   void *dz2T;     // [ntrain][H][B]
   void *dz3T;     // [ntrain][opmax][B]
-  float *outs;    // [SPL][B][OUTW] forward outputs as partial dot products, one plane per part
-                  // of hidden layer 2 (SPL = 4 at H = 256); summed by k_backward (fin_value)
+  float *outs;    // [SPL][OUTW][B] forward outputs as partial dot products, one plane per part
+                  // of hidden layer 2 (SPL = 4 at H = 256), column-major (a lane's 4 rows = one
+                  // 16-byte store); summed by k_backward (fin_value)
   float *lossp;   // [ntrain][nslab]   per-slab loss partial sums
   float *lsp;     // [nslab][A]   per-slab d(loss)/d(std) partial sums
   float *ls_snap; // [A] log_std as of the start of the step (written by k_forward's spare block)

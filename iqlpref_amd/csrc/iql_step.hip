@@ -186,16 +186,15 @@ __device__ __forceinline__ void act_store16_pair(uint16_t *plane, int col, int r
   act_store16(plane, fidx<Prec<true>>(col, k0, nkb), make_uint4(um.x, um.y, um1.x, um1.y));
 }
 
-// The forward's partial output planes (4-byte stores into a few columns of 64- to 80-byte rows: partial
-// lines).  Written through by the throughput kernel only -- A/B on one box (round 4, f4; all launches
-// write-through against none): 8 seeds per launch 225.4k -> 229.1k steps/s, 4 seeds +0.4 %, four critics
-// at batch 1024 equal, ONE seed 66.2k -> 64.4k.
+// The forward's partial output planes [part][output column][batch row]: a lane's four rows of a column
+// as one 16-byte store.  Written through by the throughput kernel only (A/B with the row-major planes
+// of 4-byte stores, round 4, f4: 8 seeds per launch 225.4k -> 229.1k steps/s, ONE seed 66.2k -> 64.4k).
 template <bool WT>
-__device__ __forceinline__ void outs_store(float *plane, size_t elem, float v) {
+__device__ __forceinline__ void outs_store4(float *plane, size_t elem, float4 v) {
   if constexpr (WT)
-    stg4_wt(plane, (uint32_t)elem * 4u, v);
+    stg16_wt(plane, (uint32_t)elem * 4u, v);
   else
-    stg(plane + elem, v);
+    stg16(plane + elem, v);
 }
 
 // relu(round(acc + bias)) of the four batch rows a lane holds for one hidden unit (MFMA C layout),
@@ -837,17 +836,18 @@ __global__ __launch_bounds__(256, PRE ? 1 : (MT >= 4 ? 2 : 3)) void k_forward(co
         }
       }
     }
+    // planes are [part][output column][batch row]: the four rows a lane holds are ONE 16-byte store, a
+    // tile's column 64 contiguous bytes (row-major planes took a 4-byte store per element into 64- to
+    // 80-byte rows: 0.9 us of the forward's end at four critics / batch 1024, stamps of round 4, g1)
     float *outp = g_outs + (size_t)(part0 + j) * B * OUTW;
+    const int row0 = slab * ROWS + 16 * m + 4 * q;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       const int col = 16 * jt + r;
-      if (jt < nt3 && col < N.out_dim) {
+      if (jt < nt3 && col < N.out_dim && row0 < B) {
         const float bias = part0 + j == 0 ? P::round(bias3[jt]) : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = slab * ROWS + 16 * m + 4 * q + i;
-          if (row < B) outs_store<false>(outp, (size_t)row * OUTW + N.out_col + col, acc3[jt][i] + bias);
-        }
+        outs_store4<false>(outp, (size_t)(N.out_col + col) * B + row0,
+                           make_float4(acc3[jt][0] + bias, acc3[jt][1] + bias, acc3[jt][2] + bias, acc3[jt][3] + bias));
       }
     }
   }
@@ -1133,16 +1133,14 @@ __global__ __launch_bounds__(512, 1) void k_forward_tp(const TrainerDesc *__rest
         for (int jt = 0; jt < 2; ++jt)
           if (jt < nt3) P::mma(a, w3[ks][jt], acc3[jt]);
       }
+      const int row0 = slab * ROWS + 16 * m + 4 * q;
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
         const int col = 16 * jt + r;
         if (jt < nt3 && col < N.out_dim) {
           const float bias = part == 0 ? P::round(bias3[jt]) : 0.f;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int row = slab * ROWS + 16 * m + 4 * q + i;
-            if (row < B) outs_store<true>(outp, (size_t)row * OUTW + N.out_col + col, acc3[jt][i] + bias);
-          }
+          outs_store4<true>(outp, (size_t)(N.out_col + col) * B + row0,
+                            make_float4(acc3[jt][0] + bias, acc3[jt][1] + bias, acc3[jt][2] + bias, acc3[jt][3] + bias));
         }
       }
     }
@@ -1314,15 +1312,18 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   // weight stream requested next.  Thread (row tid / 16, lane16 = tid % 16). ----
   const int lrow = tid >> 4, lj = tid & 15;
   const int brow = slab * SLAB + lrow;
+  // (the partial planes are [part][column][row]: for THIS phase thread -> (row tid % 16, column tid / 16 + 16 c),
+  // 16 consecutive rows of a column = 64 contiguous bytes per 16 lanes)
+  const int frow = tid & 15, fcq = tid >> 4;
   float pv[FIN_NC][SPL];
   {
-    const float *o = g_outs + (size_t)brow * OUTW;
+    const float *o = g_outs + (size_t)(slab * SLAB + frow);
 #pragma unroll
     for (int c = 0; c < FIN_NC; ++c) {
-      const int col = lj + 16 * c;
+      const int col = fcq + 16 * c;
       const unsigned cc = (unsigned)(col < OUTW ? col : OUTW - 1);  // clamped, unused beyond OUTW
 #pragma unroll
-      for (int p = 0; p < SPL; ++p) pv[c][p] = ldg(o + ((unsigned)p * (unsigned)(B * OUTW) + cc));
+      for (int p = 0; p < SPL; ++p) pv[c][p] = ldg(o + ((unsigned)p * (unsigned)OUTW + cc) * (unsigned)B);
     }
   }
   const float rew = ldg(g_rd + (size_t)brow * 2), done = ldg(g_rd + (size_t)brow * 2 + 1);
@@ -1377,14 +1378,14 @@ __device__ __forceinline__ void backward_body(const TrainerDesc *__restrict__ Dp
   // ---- finish the forward outputs of this slab (sum of the parts, rounding, tanh) ----
 #pragma unroll
   for (int c = 0; c < FIN_NC; ++c) {
-    const int col = lj + 16 * c;
+    const int col = fcq + 16 * c;
     if (col < OUTW) {
       float sum = pv[c][0];
 #pragma unroll
       for (int p = 1; p < SPL; ++p) sum += pv[c][p];
       const float v = P::round(sum);
       // the actor's mean columns carry its tanh (ref:462-470), rounded like every autocast output
-      fin[lrow * FIN_LD + col] = (col >= out_mean && col < out_mean + n_act) ? P::round(tanhf(v)) : v;
+      fin[frow * FIN_LD + col] = (col >= out_mean && col < out_mean + n_act) ? P::round(tanhf(v)) : v;
     }
   }
   __syncthreads();
@@ -1637,15 +1638,16 @@ __global__ __launch_bounds__(512, 1) void k_backward_tp(const TrainerDesc *__res
   // ---- the loss inputs first (thread (row tid / 16, lane16 = tid % 16) of its half) ----
   const int lrow = tid >> 4, lj = tid & 15;
   const int brow = slab * SLAB + lrow;
+  const int frow = tid & 15, fcq = tid >> 4;  // (the partial planes are [part][column][row]: see k_backward)
   float pv[FIN_NC][SPL];
   {
-    const float *o = g_outs + (size_t)brow * OUTW;
+    const float *o = g_outs + (size_t)(slab * SLAB + frow);
 #pragma unroll
     for (int c = 0; c < FIN_NC; ++c) {
-      const int col = lj + 16 * c;
+      const int col = fcq + 16 * c;
       const unsigned cc = (unsigned)(col < OUTW ? col : OUTW - 1);
 #pragma unroll
-      for (int p = 0; p < SPL; ++p) pv[c][p] = ldg(o + ((unsigned)p * (unsigned)(B * OUTW) + cc));
+      for (int p = 0; p < SPL; ++p) pv[c][p] = ldg(o + ((unsigned)p * (unsigned)OUTW + cc) * (unsigned)B);
     }
   }
   const float rew = ldg(g_rd + (size_t)brow * 2), done = ldg(g_rd + (size_t)brow * 2 + 1);
@@ -1703,13 +1705,13 @@ __global__ __launch_bounds__(512, 1) void k_backward_tp(const TrainerDesc *__res
   // ---- finish the forward outputs of this slab (sum of the parts, rounding, tanh) ----
 #pragma unroll
   for (int c = 0; c < FIN_NC; ++c) {
-    const int col = lj + 16 * c;
+    const int col = fcq + 16 * c;
     if (col < OUTW) {
       float sum = pv[c][0];
 #pragma unroll
       for (int p = 1; p < SPL; ++p) sum += pv[c][p];
       const float v = P::round(sum);
-      fin[lrow * FIN_LD + col] = (col >= out_mean && col < out_mean + n_act) ? P::round(tanhf(v)) : v;
+      fin[frow * FIN_LD + col] = (col >= out_mean && col < out_mean + n_act) ? P::round(tanhf(v)) : v;
     }
   }
   if (IQL_BTP_LATE == 1) {

@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # an explicitly named build is loaded as it is (no source-tag check): the diagnostic library
-os.environ["IQLHIP_LIB"] = os.path.join(ROOT, "iqlpref_amd", "libiqlhip_stamps.so")
+os.environ["IQLHIP_LIB"] = os.path.join(ROOT, "iqlpref_amd", os.environ.get("STAMP_LIB", "libiqlhip_stamps.so"))
 from iqlpref_amd import _lib  # noqa: E402
 import iqlpref_amd as ia  # noqa: E402
 import bench  # noqa: E402
