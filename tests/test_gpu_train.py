@@ -312,3 +312,22 @@ def test_train_replays_the_references_own_train_run(tmp_path, tag):
         key = f"{tag}/final/q_target/{name}"
         want, got = (d[key + "#stride37"], a.reshape(-1)[::37]) if key + "#stride37" in d.files else (d[key], a)
         assert np.abs(got - want.reshape(got.shape)).max() < (2e-6 if mode == "fp32" else 60 * 0.005 * 3e-4 * 60)
+
+
+def test_seeds_per_gpu_with_load_model_warns(tmp_path):
+    """K seeds started from ONE checkpoint differ only in their sample streams -- say so."""
+    import iqlpref_amd as ia
+    S, A, N = 29, 8, 2000
+    data = synth(N, S, A)
+    cfg = ia.TrainConfig(env="antmaze-medium-diverse-v2", max_timesteps=4, log_freq=2, eval_freq=4, batch_size=32,
+                         seed=3, device=DEV, checkpoints_path=str(tmp_path))
+    ia.train(cfg, dataset={k: v.copy() for k, v in data.items()}, state_dim=S, action_dim=A, max_action=1.0,
+             logger=lambda d, step: None, evaluate=None)
+    ck = os.path.join(cfg.checkpoints_path, "checkpoint_3.pt")
+    assert os.path.exists(ck)
+    cfg2 = ia.TrainConfig(env="antmaze-medium-diverse-v2", max_timesteps=2, log_freq=2, eval_freq=2, batch_size=32,
+                          seed=3, device=DEV, load_model=ck)
+    with pytest.warns(UserWarning, match="SAME checkpoint"):
+        trs = ia.train(cfg2, dataset={k: v.copy() for k, v in data.items()}, state_dim=S, action_dim=A,
+                       max_action=1.0, logger=lambda d, step: None, evaluate=None, seeds_per_gpu=2)
+    assert [t.total_it for t in trs] == [6, 6]  # both resumed at step 4 and ran 2 more

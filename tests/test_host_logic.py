@@ -266,3 +266,16 @@ def test_reward_model_follows_the_ranks_seed(monkeypatch):
         assert [c.seed for c in per_seed] == seeds and cfg.reward_model_path == "/models/mr_7"
     plain = ia.TrainConfig(env="antmaze-medium-diverse-v2", seed=7, reward_model_path="/models/one")
     assert all(c is plain for c in seed_configs(plain, [8, 9]))
+
+
+def test_standalone_dropout_key_is_the_seed_the_module_was_built_under():
+    """train(seeds_per_gpu=K) builds the K actors after K successive set_seed calls; each
+    keeps ITS seed as the key of its stand-alone dropout masks (a module built later must not change it)."""
+    import iqlpref_amd as ia
+    ia.set_seed(11)
+    a = ia.GaussianPolicy(5, 2, 1.0, hidden_dim=64, dropout=0.1)
+    ia.set_seed(12)
+    b = ia.GaussianPolicy(5, 2, 1.0, hidden_dim=64, dropout=0.1)
+    assert a.net._drop_seed == 11 and b.net._drop_seed == 12
+    import torch
+    assert torch.initial_seed() == 12  # (what the old key, read at call time, would have given both)
