@@ -400,11 +400,14 @@ static T *carve(char *&p, size_t n) {
 // slot i of the table belongs to XCD i & 7, row i >> 3.  `per_xcd` lists what each XCD works on; rows
 // are padded with idle slots (net = -1), which gather the next step's batch: they are numbered
 // (o0 = index, i0 = count).  `min_depth`: tables of one group share their size.
-static std::vector<UpdItem> flatten_table(const std::vector<UpdItem> (&per_xcd)[8], size_t min_depth, size_t *depth_out) {
+static std::vector<UpdItem> flatten_table(const std::vector<UpdItem> (&per_xcd)[8], size_t min_depth, size_t *depth_out,
+                                          size_t min_idle) {
   size_t depth = 0, n_real = 0;
   for (auto &v : per_xcd) depth = v.size() > depth ? v.size() : depth, n_real += v.size();
-  // a table that happens to be (almost) full gets two more rows of slots for the batch prefetch
-  if (8 * depth - n_real < 16) depth += 2;
+  // a table that happens to be (almost) full gets more rows of slots for the batch prefetch: one idle
+  // slot per 16 batch rows (a 256-thread slot gathers 16 rows per pass; batch 1024 on 16 slots took four
+  // passes of random rows out of a 288 MB buffer each -- the longest chain of the launch)
+  while (8 * depth - n_real < min_idle) ++depth;
   if (depth < min_depth) depth = min_depth;
   std::vector<UpdItem> items;
   for (size_t d = 0; d < depth; ++d)
@@ -572,7 +575,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
     std::vector<UpdItem> per_xcd[8];
     deal_items(t, 0, 1, per_xcd);  // (sizes only: D.ntrain is set, the pointers are filled in below)
     size_t depth = 0;
-    n_slots = flatten_table(per_xcd, 0, &depth).size();
+    n_slots = flatten_table(per_xcd, 0, &depth, (size_t)(B + 15) / 16).size();
   }
   t->n_items = t->own_n_items = (int)n_slots;
   add(n_slots * sizeof(UpdItem));
@@ -656,7 +659,7 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   {
     std::vector<UpdItem> per_xcd[8];
     deal_items(t, 0, 1, per_xcd);
-    items = flatten_table(per_xcd, 0, nullptr);
+    items = flatten_table(per_xcd, 0, nullptr, (size_t)(B + 15) / 16);
   }
   if (items.size() != n_slots || hipMemcpy(t->ditems, items.data(), items.size() * sizeof(UpdItem), hipMemcpyHostToDevice) !=
       hipSuccess) {
@@ -992,7 +995,7 @@ extern "C" int iqlhip_group_create(iqlhip_group **out, iqlhip_trainer *const *tr
         std::vector<UpdItem> per_xcd[8];
         deal_items(trainers[k], k, n, per_xcd);
         size_t d = 0;
-        tables[k] = flatten_table(per_xcd, depth, &d);
+        tables[k] = flatten_table(per_xcd, depth, &d, (size_t)(trainers[k]->D.B + 15) / 16);
         depth = d > depth ? d : depth;
       }
   }

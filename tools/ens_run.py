@@ -28,8 +28,9 @@ if "pen" in sys.argv[4:]:
     tr = bench.build_trainer(ia, torch, dev, 3, "bf16", n_critics=E, dims=bench.PEN["dims"],
                              dropout=bench.PEN["dropout"], hyper=bench.PEN["hyper"])
 else:
-    buf = ia.ReplayBuffer(bench.S_DIM, bench.A_DIM, 200_000, dev)
-    buf.load_d4rl_dataset(bench.synth_dataset(1, 200_000))
+    n_rows = int(os.environ.get("ENS_ROWS", "200000"))  # (bench.py's legs sample a 1M-row buffer)
+    buf = ia.ReplayBuffer(bench.S_DIM, bench.A_DIM, n_rows, dev)
+    buf.load_d4rl_dataset(bench.synth_dataset(1, n_rows))
     tr = bench.build_trainer(ia, torch, dev, 3, "bf16", n_critics=E)
 tr.train_steps(buf, min(500, n), B, return_losses=False, graph_unroll=unroll)
 torch.cuda.synchronize()

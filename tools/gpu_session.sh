@@ -20,11 +20,16 @@ for what in "$@"; do
         STAMP_GRAPH=8 STAMP_KERNEL=$k timeout -k 10 120 python tools/stamps.py bf16 > $OUT/stamps_k$k.txt 2>&1; rc=$?; stop_if_killed $rc stamps
       done
       head -40 $OUT/stamps_k2.txt ;;
+    stampsens)
+      # the E = 4 critics / batch 1024 step (BASELINE configs[4]): per-work-group stage timeline of the three kernels
+      python -m iqlpref_amd.build --stamps > $OUT/build_stamps.log 2>&1 || { echo "stamps build failed"; tail -5 $OUT/build_stamps.log; exit 1; }
+      STAMP_E=4 STAMP_B=1024 STAMP_GRAPH=8 timeout -k 10 120 python tools/stamps.py bf16 > $OUT/stamps_e4_b1024.txt 2>&1; rc=$?; stop_if_killed $rc stampsens
+      grep -v Dataset $OUT/stamps_e4_b1024.txt | cut -c1-400 ;;
     relabel)
       timeout -k 10 300 python tools/bench_relabel.py --cpu > $OUT/relabel.json 2> $OUT/relabel.err
       rc=$?; echo "relabel rc=$rc"; stop_if_killed $rc relabel; cat $OUT/relabel.json | head -120 ;;
     bench)
-      timeout -k 10 300 python bench.py --no-cpu-baseline --no-relabel > $OUT/bench.json 2> $OUT/bench.err
+      timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err
       rc=$?; echo "bench rc=$rc"; stop_if_killed $rc bench; python -c "
 import json; d=json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])
 print('value', round(d['value']), d['roofline']['step']['kernel_us'], 'frac', round(d['roofline']['frac'],3))
