@@ -534,8 +534,10 @@ __global__ __launch_bounds__(256, PRE ? 1 : (MT >= 4 ? 2 : 3)) void k_forward(co
   if (fnet == nfwd_) {
     // spare XCD slot: one thread prepares this step's Adam coefficients for k_update
     if (rest == 0 && threadIdx.x == 0) {
+      STAMP(0, 0);
       write_adam_coef(D, *Ap, Cp->ctr[0] + 1, const_cast<AdamCoef *>(&Cp->coef));
       const_cast<DevCtr *>(Cp)->coef_step = Cp->ctr[0] + 1;
+      STAMP(0, 5);
     }
     if (rest == 0 && !D.deterministic && (int)threadIdx.x < D.A)
       stg(D.ls_snap + threadIdx.x, ldg(D.params + D.off_log_std + threadIdx.x));
@@ -893,8 +895,10 @@ __global__ __launch_bounds__(512, 1) void k_forward_tp(const TrainerDesc *__rest
   if (fnet > nfwd_) return;
   if (fnet == nfwd_) {
     if (slab == 0 && threadIdx.x == 0) {
+      STAMP(0, 0);
       write_adam_coef(D, *Ap, Cp->ctr[0] + 1, const_cast<AdamCoef *>(&Cp->coef));
       const_cast<DevCtr *>(Cp)->coef_step = Cp->ctr[0] + 1;
+      STAMP(0, 5);
     }
     if (slab == 0 && !D.deterministic && (int)threadIdx.x < D.A)
       stg(D.ls_snap + threadIdx.x, ldg(D.params + D.off_log_std + threadIdx.x));
