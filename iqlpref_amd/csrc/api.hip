@@ -2,6 +2,7 @@
 // trainer workspace management, hipGraph capture of the step sequence.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -464,6 +465,26 @@ static void deal_items(const iqlhip_trainer *t, int member, int group_size, std:
       per_xcd[(x + (group ? member : 0)) & 7].push_back(it);
       ++g;
     }
+  // One seed, more items per XCD than it has CUs (E = 4: 42 on 32): the launch is resident at once and the
+  // dispatcher deals an XCD's work-groups over its CUs in order, so rows 32.. of a column land on the CUs of
+  // rows 0..: those d CUs carry two work-groups, and what a CU takes in per microsecond bounds a work-group
+  // (DESIGN.md section 4).  Put the d lightest items first and the next d lightest last, the heavy layer-2
+  // tiles in between: no CU gets two heavy ones.  (IQLHIP_ITEM_ORDER=0: the order of the networks.)
+  static const bool reorder = !(getenv("IQLHIP_ITEM_ORDER") && atoi(getenv("IQLHIP_ITEM_ORDER")) == 0);
+  if (!group && reorder) {
+    constexpr size_t CUS_PER_XCD = 32;
+    auto weight = [](const UpdItem &it) { return it.layer == 1 ? 3 : (it.layer == 0 ? 2 : 1); };  // layer-2 tile / strip / layer-3 tile
+    for (auto &col : per_xcd) {
+      if (col.size() <= CUS_PER_XCD || col.size() >= 2 * CUS_PER_XCD) continue;
+      const size_t d = col.size() - CUS_PER_XCD;
+      std::vector<UpdItem> sorted(col);
+      std::stable_sort(sorted.begin(), sorted.end(), [&](const UpdItem &a, const UpdItem &b) { return weight(a) < weight(b); });
+      std::vector<UpdItem> out(sorted.begin(), sorted.begin() + d);                 // rows 0 .. d-1: the lightest
+      out.insert(out.end(), sorted.begin() + 2 * d, sorted.end());                  // the rest (heaviest) in the middle
+      out.insert(out.end(), sorted.begin() + d, sorted.begin() + 2 * d);            // rows 32 ..: the next lightest
+      col.swap(out);
+    }
+  }
 }
 
 extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_config *cfg,

@@ -2885,10 +2885,20 @@ bool use_tp(bool bf16, const TrainerDesc &D, int n_seeds, bool backward) {
   if (!bf16 || D.H != 256 || D.B % 64 != 0) return false;
   if (backward && forced_b >= 0) return forced_b != 0;
   if (forced >= 0) return forced != 0;
-  // measured (round 4, d2, write-through activation stores): four critics at batch 1024 (11,264 row-
-  // evaluations per launch) 31.6k -> 35.3k steps/s, 8 seeds at batch 256 (14,336) 200.9k -> 220.3k; 4 seeds
-  // (7,168) 168.0k -> 152.6k, one seed 66.1k -> 50.4k: the throughput kernels from ~10,000 on
-  return (int64_t)D.B * n_seeds * D.nfwd >= 10000;
+  // The throughput kernels are one eight-wave work-group per CU, all resident at once: they win while
+  // their work-groups fill a good part of the 256 CUs and lose beyond them (two rounds) and far below
+  // (nothing covers a lone work-group's latency).  Measured (round 4, tools/tp_matrix.sh and d2 / g4;
+  // steps/s old kernels -> throughput forward + old backward -> both):
+  //   forward work-groups = evaluations x batch / 64 x seeds, backward = trained nets x batch / 32 x seeds
+  //   E = 3 / batch 256 (36 / 40) 56.4k -> 52.7k -> 47.9k     E = 4 / 256 (44 / 48) 52.7k -> 51.6k -> 46.3k
+  //   2 seeds (56 / 64) 110.6k -> 102.5k -> 89.2k            E = 8 / 256 (76 / 80) 41.4k -> 44.3k -> 42.9k
+  //   E = 4 / 512 (88 / 96) 46.0k -> 47.8k -> 44.1k           4 seeds (112 / 128) 167.0k -> 167.3k -> 154.7k
+  //   TwinQ / 1024 (112 / 128) 48.6k -> 48.8k -> 44.4k        E = 3 / 1024 (144 / 160) 35.9k -> 38.8k -> 40.7k
+  //   E = 4 / 1024 (176 / 192) 31.6k -> 34.4k -> 37.4k        8 seeds (224 / 256) 200.9k -> 223.4k -> 223.9k
+  //   E = 8 / 1024 (304 / 320) 24.8k -> 24.4k -> 23.9k
+  const int64_t fwd_wgs = (int64_t)D.nfwd * (D.B / 64) * n_seeds, bwd_wgs = (int64_t)D.ntrain * (D.B / 32) * n_seeds;
+  const bool fwd_tp = fwd_wgs >= 72 && fwd_wgs <= 256;
+  return backward ? (fwd_tp && bwd_wgs >= 144 && bwd_wgs <= 256) : fwd_tp;
 }
 // once per trainer (iqlhip_trainer_create, outside any stream capture): k_forward_tp's 64-row slabs
 // take more than the 64 KB of dynamic LDS a kernel may use by default

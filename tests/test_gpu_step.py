@@ -481,6 +481,48 @@ def test_seed_group_at_headline_shapes(gh, mode, n_seeds):
     group.close()
 
 
+@pytest.mark.parametrize("kind", ["pen_dropout", "cheetah_deterministic"])
+def test_seed_group_of_eight_on_the_throughput_kernels(gh, kind):
+    """Round 4: launches of 8 seeds at H = 256 / batch 256 run on k_forward_tp / k_backward_tp (224 / 256
+    work-groups).  Their dropout instantiation (Philox masks of the actor's two Dropout layers, pen shapes:
+    in_dim 69 -> three layer-1 k-steps, 24 outputs -> two layer-3 tiles) and the deterministic-policy branch
+    must give every seed the bits of the seed alone, which runs on k_forward / k_backward."""
+    import iqlpref_amd as ia
+    S, A, det, drop = (45, 24, False, 0.1) if kind == "pen_dropout" else (17, 6, True, None)
+    rng = np.random.default_rng(4)
+    n = 2000
+    data = {"observations": rng.standard_normal((n, S)).astype(np.float32),
+            "actions": rng.uniform(-1, 1, (n, A)).astype(np.float32), "rewards": rng.standard_normal(n).astype(np.float32),
+            "next_observations": rng.standard_normal((n, S)).astype(np.float32),
+            "terminals": (rng.uniform(size=n) < 0.02).astype(np.float32)}
+    buf = ia.ReplayBuffer(S, A, n, gh.DEV)
+    buf.load_d4rl_dataset(data)
+
+    def make(seed):
+        torch.manual_seed(seed)
+        q, v = ia.TwinQ(S, A).to(gh.DEV), ia.ValueFunction(S).to(gh.DEV)
+        actor = (ia.DeterministicPolicy if det else ia.GaussianPolicy)(S, A, 1.0, dropout=drop).to(gh.DEV)
+        return ia.ImplicitQLearning(
+            max_action=1.0, actor=actor, actor_optimizer=torch.optim.Adam(actor.parameters(), lr=3e-4), q_network=q,
+            q_optimizer=torch.optim.Adam(q.parameters(), lr=3e-4), v_network=v,
+            v_optimizer=torch.optim.Adam(v.parameters(), lr=3e-4), iql_tau=0.8, beta=3.0, max_steps=1000,
+            device=gh.DEV, precision="bf16", seed=seed)
+
+    seeds = tuple(range(21, 29))
+    alone = [make(s) for s in seeds]
+    want = [t.train_steps(buf, 9, 256, graph_unroll=0).cpu().numpy() for t in alone]
+    group = ia.SeedGroup([make(s) for s in seeds], mode="group")
+    got = group.train_steps(buf, 9, 256, return_losses=True, graph_unroll=3)
+    group.synchronize()
+    for w, g, ta, tg in zip(want, got, alone, group.trainers):
+        assert np.isfinite(w).all()
+        np.testing.assert_array_equal(w, g.cpu().numpy())
+        assert torch.equal(ta._params, tg._params) and torch.equal(ta._target, tg._target)
+        assert torch.equal(ta._exp_avg, tg._exp_avg) and torch.equal(ta._exp_avg_sq, tg._exp_avg_sq)
+    assert not np.array_equal(want[0], want[1])
+    group.close()
+
+
 def test_seed_group_split_uneven_and_cu_slice_streams(gh):
     """mode="split" with three seeds (sub-groups of two and one) on the CU-slice streams, driven
     with per-seed injected indices: bit-identical to the seeds alone.  The C entry point refuses
