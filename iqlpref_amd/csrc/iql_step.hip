@@ -163,8 +163,9 @@ __device__ __forceinline__ void act_store8_fwd(uint16_t *base, size_t elem, uint
 // IQL_WT_ACT16: these 16-byte stores leave write-through (sc0 sc1).  A wave's store instruction covers one
 // whole 1 KiB fragment (8 full lines), so nothing is merged in L2 anyway, and what a kernel leaves dirty
 // is written back at its END, by the L2s of the few XCDs that hold it: in-kernel stamps (round 4, four
-// critics at batch 1024) show the last forward work-group done 5.4 us after the first started and the
-// first backward work-group starting at +12.1 us -- 7 MB of activations leaving six L2s.
+// critics at batch 1024, plain stores) show the last forward work-group done 7.0 us after the first
+// started and the first backward work-group stamping at +12.3 us -- 7 MB of activations leaving six L2s;
+// with these stores the two are 1.6 us apart.
 // A/B on one box (round 4, d2): four critics at batch 1024 31.2k -> 35.3k steps/s, 8 seeds per launch
 // 208.7k -> 220.3k (throughput kernels), 4 seeds 156.5k -> 168.0k (k_forward<.., 2, 2>), one seed
 // unchanged (66.1k: its 16-row work-groups have no tile pairs).  -DIQL_WT_ACT16=0 builds plain stores.

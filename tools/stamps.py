@@ -105,8 +105,10 @@ for k in range(3):
         for a_, b_ in zip(order[:-1], order[1:]):
             dt = (ww[:, b_] - ww[:, a_]) * 10
             line += f" {a_}->{b_} med {np.median(dt):6.0f} max {dt.max():6.0f} |"
-        tot = (ww[:, slots[-1]] - ww[:, slots[0]]) * 10
-        end = (ww[:, slots[-1]] - t0) * 10
+        # (slots are numbered in the order they were added to the source, not in time: the work-group's end
+        # is its LATEST stamp)
+        tot = (ww[:, list(slots)].max(axis=1) - ww[:, slots[0]]) * 10
+        end = (ww[:, list(slots)].max(axis=1) - t0) * 10
         line += f" total med {np.median(tot):6.0f} max {tot.max():6.0f}; end max {end.max():6.0f}"
         print(line)
 
