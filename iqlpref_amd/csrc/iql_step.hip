@@ -962,6 +962,14 @@ __global__ __launch_bounds__(512, 1) void k_forward_tp(const TrainerDesc *__rest
           w1[ks][jj] = ldg16(W1w + (size_t)(jj * nk1 + ks) * 64 * P::EPV + lane * P::EPV);
       }
     }
+  }
+  // IQL_FTP_LATE: where the 136 KB of W2 / W3 fragments enter the vector-memory queue -- 0: up front (the
+  // waves stall issuing them and reach the input barrier late); 1: behind the input barrier, ahead of the
+  // layer-1 product; 2: behind the layer-1 product (k_forward's order)
+#ifndef IQL_FTP_LATE
+#define IQL_FTP_LATE 0
+#endif
+  auto load_w23 = [&]() {
 #pragma unroll
     for (int jj = 0; jj < TPW; ++jj) {
       const T *W2w = reinterpret_cast<const T *>(N.w2c) + (size_t)(tile0 + jj) * NK2 * 64 * P::EPV;
@@ -974,7 +982,8 @@ __global__ __launch_bounds__(512, 1) void k_forward_tp(const TrainerDesc *__rest
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt)
         if (jt < nt3) w3[ks][jt] = ldg16(W3w + (size_t)(jt * NK2 + ks) * 64 * P::EPV + lane * P::EPV);
-  }
+  };
+  if (IQL_FTP_LATE == 0) load_w23();
   STAMP(0, 1);
 
   // ---- layer-1 input into LDS ----
@@ -993,6 +1002,11 @@ __global__ __launch_bounds__(512, 1) void k_forward_tp(const TrainerDesc *__rest
   }
   __syncthreads();
   STAMP(0, 2);
+  if (IQL_FTP_LATE == 1) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_w23();
+    __builtin_amdgcn_sched_barrier(0);
+  }
 
   // DROP = false: the lean bf16 epilogues only (relu_bias_bf16x4); the instantiation with dropout
   // carries the Philox masks.  The host picks by the trainer's has_dropout; a network without dropout
@@ -1017,6 +1031,11 @@ __global__ __launch_bounds__(512, 1) void k_forward_tp(const TrainerDesc *__rest
       }
     }
     STAMP(0, 6);
+    if (IQL_FTP_LATE == 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_w23();
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int jj = 0; jj < TPW; ++jj) {
       const int col = 16 * (tile0 + jj) + r;
