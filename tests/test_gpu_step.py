@@ -360,10 +360,17 @@ def test_errors(gh):
     # BASELINE config 5: E-way critic ensemble (no reference implementation: the oracle's E-way
     # generalisation of ref:595-613 is the checker, pinned to the reference at E = 2 only)
     (29, 8, 256, 1024, False, None, 4), (29, 8, 256, 256, False, None, 3), (17, 6, 128, 48, True, None, 8),
-    (11, 3, 64, 32, False, 0.1, 5)])
+    (11, 3, 64, 32, False, 0.1, 5),
+    # round 4: the launch shapes that pick the throughput kernels one seed at a time -- both (E = 3 at batch
+    # 1024, deterministic policy), the forward only (E = 8 at batch 256: ten trained nets; pen shapes with
+    # dropout at batch 1024: its DROP instantiation with Philox / injected masks)
+    (17, 6, 256, 1024, True, None, 3), (29, 8, 256, 256, False, None, 8), (45, 24, 256, 1024, False, 0.1, 2)])
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_shapes_beyond_the_goldens_vs_oracle(gh, S, A, H, B, det, drop, E, mode):
     """BASELINE configs 3/5 shapes and odd sizes: HIP vs the (reference-pinned) oracle."""
+    if mode == "fp32" and (S, A, H, B, det, drop, E) in ((17, 6, 256, 1024, True, None, 3), (29, 8, 256, 256, False, None, 8),
+                                                         (45, 24, 256, 1024, False, 0.1, 2)):
+        pytest.skip("round-4 cases: they exist for the throughput kernels, which are bf16 only")
     import iqlpref_amd as ia
     rng = np.random.default_rng(B)
     N = 2000
@@ -419,8 +426,9 @@ def test_shapes_beyond_the_goldens_vs_oracle(gh, S, A, H, B, det, drop, E, mode)
             # no element may move further from the oracle than the steps themselves (K * lr).
             diff = np.abs(t.cpu().numpy() - opar[k])
             assert diff.max() < K * 3e-4 * 1.01 + 2e-6, f"{name}/{k}: max {diff.max():.3e}"
-            if mode == "fp32":  # and all but a vanishing fraction agree to fp32 rounding
-                assert (diff > 2e-6).mean() < 1e-4, f"{name}/{k}: {(diff > 2e-6).mean():.2e} of elements off"
+            if mode == "fp32":  # and all but a vanishing fraction agree to fp32 rounding (a small tensor may
+                # hold a few such entries: 1 of the 4,352 of a 256 x 17 first layer is 2.3e-4 of it)
+                assert (diff > 2e-6).sum() <= max(3, 1e-4 * diff.size), f"{name}/{k}: {(diff > 2e-6).mean():.2e} of elements off"
 
 
 @pytest.mark.parametrize("mode", ["group", "streams", "split"])
