@@ -109,3 +109,45 @@ def test_full_size_relabel_properties(big):
     srt = preds[:, :4096].sort(0).values[:5].mean(0)
     np.testing.assert_allclose(cvar_tail_mean_device(preds, 5)[:4096].cpu().numpy(), srt.cpu().numpy(),
                                rtol=1e-5, atol=1e-6)
+
+
+def test_full_length_run_of_a_million_updates():
+    """BASELINE run length: 1,000,000 updates (configs/offline/iql/antmaze/medium_diverse_v2.yaml:9) at the
+    headline shapes -- ~15 s on an MI355X.  The run stays finite, counts its steps, and ends the actor's
+    cosine schedule where torch's CosineAnnealingLR does (lr -> 0 at T_max, ref:571,637); a checkpoint
+    taken at the end holds the step count in every Adam state entry."""
+    import iqlpref_amd as ia
+    S, A, N = 29, 8, 1_000_000
+    rng = np.random.default_rng(0)
+    data = {"observations": rng.standard_normal((N, S), dtype=np.float32),
+            "actions": rng.uniform(-1, 1, (N, A)).astype(np.float32),
+            "rewards": (rng.uniform(size=N) < 0.01).astype(np.float32) - 1.0,
+            "next_observations": rng.standard_normal((N, S), dtype=np.float32),
+            "terminals": (rng.uniform(size=N) < 1e-3).astype(np.float32)}
+    buf = ia.ReplayBuffer(S, A, N, DEV)
+    buf.load_d4rl_dataset(data)
+    torch.manual_seed(0)
+    q, v, actor = ia.TwinQ(S, A).to(DEV), ia.ValueFunction(S).to(DEV), ia.GaussianPolicy(S, A, 1.0).to(DEV)
+    T = 1_000_000
+    tr = ia.ImplicitQLearning(
+        max_action=1.0, actor=actor, actor_optimizer=torch.optim.Adam(actor.parameters(), lr=3e-4), q_network=q,
+        q_optimizer=torch.optim.Adam(q.parameters(), lr=3e-4), v_network=v,
+        v_optimizer=torch.optim.Adam(v.parameters(), lr=3e-4), iql_tau=0.9, beta=10.0, max_steps=T, device=DEV, seed=0)
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(T // 50_000 - 1):
+        tr.train_steps(buf, 50_000, 256, return_losses=False)
+    last = tr.train_steps(buf, 50_000, 256).cpu().numpy()
+    dt = time.perf_counter() - t0
+    assert tr.total_it == T and np.isfinite(last).all()
+    assert torch.isfinite(tr._params).all() and torch.isfinite(tr._exp_avg_sq).all() and torch.isfinite(tr._target).all()
+    # the schedule: lr(T_max) = 0, and the last step ran at lr(T_max - 1) > 0 (the scheduler steps AFTER the optimiser)
+    assert abs(tr.actor_optimizer.param_groups[0]["lr"]) < 1e-18
+    assert tr.actor_lr_schedule.last_epoch == T
+    sd = tr.state_dict()
+    assert sd["total_it"] == T and all(float(st["step"]) == T for st in sd["q_optimizer"]["state"].values())
+    # value / q losses of a fitted run are small and positive; the critic's target has moved with it
+    assert 0 < last[:, 0].mean() < 1.0 and 0 < last[:, 1].mean() < 10.0
+    assert not torch.equal(tr._target, tr._params[:tr._n_target])  # Polyak average, not a copy
+    assert dt < 120, f"1M updates took {dt:.0f} s"
