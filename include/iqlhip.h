@@ -45,11 +45,15 @@ const char *iqlhip_build_tag(void);
 /* ------------------------------------------------------------------------ */
 /* Shape envelope (everything outside returns IQLHIP_ERR_UNSUPPORTED with a   */
 /* message; every YAML under the reference's configs/offline/iql/ fits):      */
-/*   trainer   n_hidden = 2 (three Linear layers per net), ReLU hidden         */
-/*             activations, hidden_dim in {64, 128, 256}, batch_size a         */
-/*             multiple of 16, state_dim + action_dim <= 128, action_dim <= 32,*/
-/*             2..8 critics, plain Adam (no weight decay / amsgrad), one       */
-/*             (beta1, beta2, eps) for the three optimisers;                   */
+/*   trainer   ReLU hidden activations, one width for all hidden layers,       */
+/*             n_hidden 1..6, hidden_dim 1..1024, batch_size a multiple of 16, */
+/*             state_dim + action_dim <= 128, action_dim <= 32, 2..8 critics,  */
+/*             plain Adam (no weight decay / amsgrad), one (beta1, beta2, eps) */
+/*             for the three optimisers.  n_hidden = 2 with hidden_dim 64, 128 */
+/*             or 256 (the reference's default and every shipped YAML) runs on */
+/*             the tuned three-kernel step; every other shape on the general   */
+/*             layer-wise step (csrc/iql_deep.hip: same arithmetic, plain      */
+/*             launches only, no seed groups);                                 */
 /*   MLP fwd   1..8 layers, every width in [1, 256];                           */
 /*   CVaR      1 <= n_tail <= S <= 2400;                                       */
 /*   PT        embd_dim 64, ONE GPT-2 block, num_heads a power of two <= 16,   */
@@ -153,7 +157,7 @@ int iqlhip_replay_sample(const iqlhip_replay_view *view, int32_t batch,
 
 typedef struct {
   int32_t state_dim, action_dim;
-  int32_t hidden_dim;    /* 64, 128 or 256; n_hidden is fixed at 2                 */
+  int32_t hidden_dim;    /* 1..1024 (ref:417-449 MLP: one width for all hidden layers) */
   int32_t batch_size;    /* multiple of 16                                        */
   int32_t deterministic; /* 1: DeterministicPolicy (ref:485), 0: Gaussian (ref:452)*/
   int32_t precision;     /* IQLHIP_PREC_*                                         */
@@ -168,18 +172,22 @@ typedef struct {
                             sum(mse)/E (ref:606 generalised; SURVEY 8 "config 5")    */
   int32_t polyak_form;   /* target update: 0 = tp.lerp_(sp, tau) (offline/iql.py:127-129),
                             1 = (1 - tau) tp + tau sp (custom_offline/iql.py:85-87)      */
+  int32_t n_hidden;      /* hidden layers per network (ref:458-459, 519, 538: n_hidden);
+                            0 = the reference's default 2; 1..6                           */
 } iqlhip_trainer_config;
 
 /* Number of fp32 elements of the arenas (n_params, n_target: they include the
  * alignment padding, every tensor starts on a 128-byte line; padding elements
  * are never read or written) and the element offset of every tensor in the
- * parameter arena.  Order of the 6(E+2)+1 offsets (25 for TwinQ): for net in
- * (q1, .., qE, v, actor): W1[H][in] b1[H] W2[H][H] b2[H] W3[out][H] b3[out];
- * then actor log_std[A] (offset -1 when deterministic); unused slots are -1.
+ * parameter arena.  Order of the 2 L (E+2) + 1 offsets, L = n_hidden + 1 Linear
+ * layers (25 offsets for TwinQ with two hidden layers): for net in (q1, .., qE, v,
+ * actor): W_1[H][in] b_1[H] W_2[H][H] b_2[H] ... W_L[out][H] b_L[out]; then actor
+ * log_std[A] (offset -1 when deterministic); unused slots are -1.
  * Torch [out][in] row-major layouts.  The target arena uses the q1..qE part of
  * the same layout.                                                           */
 #define IQLHIP_MAX_CRITICS 8
-#define IQLHIP_N_TENSORS (6 * (IQLHIP_MAX_CRITICS + 2) + 1)
+#define IQLHIP_MAX_HIDDEN 6
+#define IQLHIP_N_TENSORS (2 * (IQLHIP_MAX_HIDDEN + 1) * (IQLHIP_MAX_CRITICS + 2) + 1)
 int iqlhip_arena_layout(const iqlhip_trainer_config *cfg, int64_t offsets[IQLHIP_N_TENSORS],
                         int64_t *n_params, int64_t *n_target);
 
@@ -199,6 +207,10 @@ typedef struct iqlhip_trainer iqlhip_trainer;
 int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_config *cfg,
                           const iqlhip_arenas *arenas);
 int iqlhip_trainer_destroy(iqlhip_trainer *t);
+
+/* Which step runs this trainer's shape: 0 = the tuned three-kernel step (csrc/iql_step.hip),
+ * 1 = the general layer-wise step (csrc/iql_deep.hip).  See the shape envelope above.        */
+int iqlhip_trainer_step_kind(iqlhip_trainer *t, int32_t *kind);
 
 /* Rebuild the compute-precision weight copies from the fp32 masters (call
  * after the arenas were written from outside: init, load_state_dict).        */

@@ -13,11 +13,12 @@ LIB_PATH = os.environ.get("IQLHIP_LIB") or os.path.join(HERE, "libiqlhip.so")
 PREC_FP32 = 0
 PREC_BF16 = 1
 MAX_CRITICS = 8
-N_TENSORS = 6 * (MAX_CRITICS + 2) + 1
+MAX_HIDDEN = 6
+N_TENSORS = 2 * (MAX_HIDDEN + 1) * (MAX_CRITICS + 2) + 1
 MLP_MAX_LAYERS = 8
 MAX_GROUP = 16
 ACT_FLAX_BASE = 8  # iqlhip_mlp_desc activation code 8 + i = entry i of reward_models/q_mlp.py:121-130
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ERR_INVALID = -1
 ERR_HIP = -2
@@ -41,7 +42,7 @@ class TrainerConfig(C.Structure):
                 ("adam_beta1", C.c_double), ("adam_beta2", C.c_double),
                 ("adam_eps", C.c_double),
                 ("cosine_t_max", C.c_int64), ("seed", C.c_uint64),
-                ("n_critics", C.c_int32), ("polyak_form", C.c_int32)]
+                ("n_critics", C.c_int32), ("polyak_form", C.c_int32), ("n_hidden", C.c_int32)]
 
 
 class Arenas(C.Structure):
@@ -93,6 +94,7 @@ SYMBOLS = {
                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "iqlhip_trainer_create": (C.c_int, [C.POINTER(P), C.POINTER(TrainerConfig), C.POINTER(Arenas)]),
     "iqlhip_trainer_destroy": (C.c_int, [P]),
+    "iqlhip_trainer_step_kind": (C.c_int, [P, C.POINTER(C.c_int32)]),
     "iqlhip_trainer_sync_weights": (C.c_int, [P, P]),
     "iqlhip_trainer_set_step": (C.c_int, [P, C.c_int64]),
     "iqlhip_trainer_get_step": (C.c_int, [P, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HEADER = os.path.join(HERE, "..", "include", "iqlhip.h")
-SOURCES = ["api.hip", "iql_step.hip", "buffer.hip", "mlp_f32.hip", "cvar.hip", "pt.hip", "prep.hip"]
+SOURCES = ["api.hip", "iql_step.hip", "iql_deep.hip", "buffer.hip", "mlp_f32.hip", "cvar.hip", "pt.hip", "prep.hip"]
 LIB = os.path.join(HERE, "libiqlhip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
          # kernarg preload: the first 16 kernarg dwords (the descriptor pointers) arrive in SGPRs

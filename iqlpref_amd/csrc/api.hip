@@ -13,9 +13,20 @@
 
 #include "../../include/iqlhip.h"
 #include "common.h"
+#include "iql_deep.h"
 #include "iql_step.h"
+#include "step_math.h"
 
 namespace iqlhip {
+// the general layer-wise step (iql_deep.hip)
+struct DeepTrainer;
+bool deep_shape_ok(const iqlhip_trainer_config &, int n_hidden, const char **why);
+hipError_t deep_create(DeepTrainer **, const iqlhip_trainer_config &, int n_hidden, const iqlhip_arenas &,
+                       const int64_t *offsets);
+void deep_destroy(DeepTrainer *);
+hipError_t deep_sync_weights(DeepTrainer *, hipStream_t);
+hipError_t deep_step(DeepTrainer *, const DeepStep &, hipStream_t, hipEvent_t *ev);
+hipError_t deep_infer(DeepTrainer *, int which, const float *s, const float *a, int64_t n, float *out, hipStream_t);
 int layer2_parts(int H);
 hipError_t launch_forward(bool, const TrainerDesc &, const TrainerDesc *, const DevArgs *, const DevCtr *,
                           int n_seeds, hipStream_t);
@@ -97,7 +108,7 @@ static hipError_t capture_stream(hipStream_t *out) {
   return hipSuccess;
 }
 
-extern "C" int iqlhip_abi_version(void) { return 5; }
+extern "C" int iqlhip_abi_version(void) { return 6; }
 // sha256 prefix of csrc/* + include/iqlhip.h, stamped by iqlpref_amd/build.py: the Python side
 // refuses a library whose tag does not match the sources it sits beside
 #ifndef IQLHIP_BUILD_TAG
@@ -241,6 +252,10 @@ struct Throttle {
 struct iqlhip_trainer {
   iqlhip_trainer_config cfg;
   iqlhip_arenas arenas;
+  // shapes outside the tuned step's (n_hidden != 2 or another width): the general layer-wise step;
+  // of the members below only cfg, the learning rates, total_it, the timing events, the throttle and
+  // batch_rows are in use then
+  DeepTrainer *deep = nullptr;
   TrainerDesc D;
   bool bf16;
   void *ws = nullptr;
@@ -291,23 +306,32 @@ struct iqlhip_trainer {
 };
 
 static_assert(MAX_CRITICS == IQLHIP_MAX_CRITICS, "iql_step.h and iqlhip.h disagree");
-static_assert(IQLHIP_N_TENSORS == 6 * MAX_TRAIN + 1, "offset table size");
+static_assert(IQLHIP_N_TENSORS == 2 * DEEP_MAX_LIN * MAX_TRAIN + 1, "offset table size");
+static_assert(IQLHIP_MAX_HIDDEN + 1 == DEEP_MAX_LIN, "iql_deep.h and iqlhip.h disagree");
 // number of critics: 0 in the config means the reference's TwinQ
 static int n_critics(const iqlhip_trainer_config &c) { return c.n_critics > 0 ? c.n_critics : 2; }
+// hidden layers: 0 in the config means the reference's default (ref:458-459, 519, 538)
+static int n_hidden(const iqlhip_trainer_config &c) { return c.n_hidden > 0 ? c.n_hidden : 2; }
+// which step runs this shape: the tuned three-kernel one or the general layer-wise one
+static bool is_deep(const iqlhip_trainer_config &c) {
+  return n_hidden(c) != 2 || (c.hidden_dim != 64 && c.hidden_dim != 128 && c.hidden_dim != 256) ||
+         getenv("IQLHIP_FORCE_GENERAL") != nullptr;  // (tests: the general step on a shape the tuned one takes)
+}
 
 static int check_cfg(const iqlhip_trainer_config *c) {
   if (!c) return fail(IQLHIP_ERR_INVALID, "null config");
   if (c->n_critics < 0 || c->n_critics == 1 || c->n_critics > MAX_CRITICS)
     return fail(IQLHIP_ERR_UNSUPPORTED, "n_critics %d: 0 (= 2) or 2..%d", c->n_critics, MAX_CRITICS);
   if (c->state_dim <= 0 || c->action_dim <= 0) return fail(IQLHIP_ERR_INVALID, "bad dims");
-  if (c->hidden_dim != 64 && c->hidden_dim != 128 && c->hidden_dim != 256)
-    return fail(IQLHIP_ERR_UNSUPPORTED, "hidden_dim %d: kernels are built for 64, 128 and 256", c->hidden_dim);
+  if (c->n_hidden < 0) return fail(IQLHIP_ERR_INVALID, "n_hidden must be >= 0");
+  if (const char *why = nullptr; !deep_shape_ok(*c, n_hidden(*c), &why))
+    return fail(IQLHIP_ERR_UNSUPPORTED, "n_hidden %d, hidden_dim %d: %s", n_hidden(*c), c->hidden_dim, why);
   if (c->batch_size < 16 || c->batch_size % 16)
     return fail(IQLHIP_ERR_UNSUPPORTED, "batch_size %d: must be a positive multiple of 16", c->batch_size);
   if (c->action_dim > 32) return fail(IQLHIP_ERR_UNSUPPORTED, "action_dim %d > 32", c->action_dim);
   if (c->state_dim + c->action_dim > 128) return fail(IQLHIP_ERR_UNSUPPORTED, "state_dim+action_dim > 128");
   // the misc block of k_update sums the per-slab loss partials in its LDS
-  if ((c->batch_size / 16) * (n_critics(*c) + 2 + (c->deterministic ? 0 : c->action_dim)) + n_critics(*c) + 2 >
+  if (!is_deep(*c) && (c->batch_size / 16) * (n_critics(*c) + 2 + (c->deterministic ? 0 : c->action_dim)) + n_critics(*c) + 2 >
       update_lds_floats())
     return fail(IQLHIP_ERR_UNSUPPORTED, "batch_size %d too large for action_dim %d", c->batch_size,
                 c->action_dim);
@@ -335,26 +359,29 @@ static Layout make_layout(const iqlhip_trainer_config &c) {
   constexpr int64_t ALIGN = 32;
   Layout L;
   int64_t o = 0, cnt = 0;
-  const int H = c.hidden_dim;
+  const int H = c.hidden_dim, NL = n_hidden(c) + 1;
   const int E = n_critics(c), ntrain = E + 2;
   for (int k = 0; k < IQLHIP_N_TENSORS; ++k) L.off[k] = -1;
   for (int n = 0; n < ntrain; ++n) {
     int in, out;
     net_dims(c, n, &in, &out);
-    const int64_t sz[6] = {(int64_t)H * in, H, (int64_t)H * H, H, (int64_t)out * H, out};
-    for (int k = 0; k < 6; ++k) {
-      o = (o + ALIGN - 1) / ALIGN * ALIGN;
-      L.off[n * 6 + k] = o;
-      o += sz[k];
-      cnt += sz[k];
+    for (int l = 0; l < NL; ++l) {
+      const int64_t rows = l == NL - 1 ? out : H, cols = l == 0 ? in : H;
+      const int64_t sz[2] = {rows * cols, rows};  // W_l [rows][cols], b_l [rows]
+      for (int k = 0; k < 2; ++k) {
+        o = (o + ALIGN - 1) / ALIGN * ALIGN;
+        L.off[(n * NL + l) * 2 + k] = o;
+        o += sz[k];
+        cnt += sz[k];
+      }
     }
     if (n == E - 1) L.n_target = o, L.true_target = cnt;
   }
   if (c.deterministic) {
-    L.off[ntrain * 6] = -1;
+    L.off[ntrain * NL * 2] = -1;
   } else {
     o = (o + ALIGN - 1) / ALIGN * ALIGN;
-    L.off[ntrain * 6] = o;
+    L.off[ntrain * NL * 2] = o;
     o += c.action_dim;
     cnt += c.action_dim;
   }
@@ -380,11 +407,11 @@ extern "C" int iqlhip_step_cost(const iqlhip_trainer_config *cfg, double *bytes,
   // gather + (read p,g,m,v; write g,p,m,v) per trained parameter + target r/w
   if (bytes) *bytes = 4.0 * B * (2 * S + A + 2) + 32.0 * (double)L.true_params + 8.0 * (double)L.true_target;
   if (flops) {
-    const double E = n_critics(*cfg);
-    const double wv = S * H + H * H + H, wq = (S + A) * H + H * H + H, wa = S * H + H * H + H * A;
+    const double E = n_critics(*cfg), HH = (n_hidden(*cfg) - 1) * H * H;  // hidden-to-hidden matrices
+    const double wv = S * H + HH + H, wq = (S + A) * H + HH + H, wa = S * H + HH + H * A;
     const double fwd = 2 * wv + 2 * E * wq + wa;                 // V twice, target+online critics, actor
     const double dw = wv + E * wq + wa;                          // weight gradients
-    const double dx = (H * H + H) * (E + 1) + (H * H + H * A);   // input gradients of layers 3, 2
+    const double dx = (HH + H) * (E + 1) + (HH + H * A);         // input gradients of every layer but the first
     *flops = 2.0 * B * (fwd + dw + dx);
   }
   return 0;
@@ -501,6 +528,19 @@ extern "C" int iqlhip_trainer_create(iqlhip_trainer **out, const iqlhip_trainer_
   t->bf16 = cfg->precision == IQLHIP_PREC_BF16;
   t->lr_q = cfg->lr_q, t->lr_v = cfg->lr_v, t->lr_a_base = cfg->lr_actor;
   const Layout L = make_layout(*cfg);
+  if (is_deep(*cfg)) {
+    memset(&t->D, 0, sizeof(t->D));
+    t->D.E = n_critics(*cfg);
+    const size_t rows_bytes = (size_t)cfg->batch_size * iqlhip_replay_row_stride(cfg->state_dim, cfg->action_dim) * 4;
+    hipError_t e = deep_create(&t->deep, *cfg, n_hidden(*cfg), *ar, L.off);
+    if (e == hipSuccess && (e = hipMalloc((void **)&t->batch_rows, rows_bytes)) != hipSuccess) deep_destroy(t->deep);
+    if (e != hipSuccess) {
+      delete t;
+      return fail(e == hipErrorOutOfMemory ? IQLHIP_ERR_NOMEM : IQLHIP_ERR_HIP, "general step: %s", hipGetErrorString(e));
+    }
+    *out = t;
+    return 0;
+  }
   const int S = cfg->state_dim, A = cfg->action_dim, H = cfg->hidden_dim, B = cfg->batch_size;
   const int es = t->bf16 ? 2 : 4, KM = t->bf16 ? 32 : 16;
   TrainerDesc &D = t->D;
@@ -733,13 +773,27 @@ extern "C" int iqlhip_trainer_destroy(iqlhip_trainer *t) {
   for (auto &e : t->ev)
     if (e) (void)hipEventDestroy(e);
   t->throttle.destroy();
+  if (t->deep) {
+    deep_destroy(t->deep);
+    (void)hipFree(t->batch_rows);
+  }
   if (t->ws) (void)hipFree(t->ws);
   delete t;
   return 0;
 }
 
+extern "C" int iqlhip_trainer_step_kind(iqlhip_trainer *t, int32_t *kind) {
+  if (!t || !kind) return fail(IQLHIP_ERR_INVALID, "null argument");
+  *kind = t->deep ? 1 : 0;
+  return 0;
+}
+
 extern "C" int iqlhip_trainer_sync_weights(iqlhip_trainer *t, void *stream) {
   if (!t) return fail(IQLHIP_ERR_INVALID, "null trainer");
+  if (t->deep) {
+    HIP_TRY(deep_sync_weights(t->deep, (hipStream_t)stream));
+    return 0;
+  }
   HIP_TRY(launch_sync_weights(t->bf16, t->ddesc, (hipStream_t)stream));
   return 0;
 }
@@ -750,6 +804,7 @@ extern "C" int iqlhip_trainer_set_step(iqlhip_trainer *t, int64_t total_it) {
   // non-blocking stream can race the counter write below
   HIP_TRY(hipDeviceSynchronize());
   t->total_it = total_it;
+  if (t->deep) return 0;  // (the general step takes its step count with every launch)
   DevCtr c;
   memset(&c, 0, sizeof(c));
   c.ctr[0] = total_it, c.ctr[1] = total_it;
@@ -838,8 +893,43 @@ static hipError_t push_args(iqlhip_trainer *t, const DevArgs &args_in, int64_t n
   return hipSuccess;
 }
 
+// The general step: three plain launches per step, the step's arguments (index / mask / loss slices,
+// Adam coefficients computed here in double) by value.  graph_unroll is ignored.
+static int run_steps_deep(iqlhip_trainer *t, const DevArgs &a, int64_t n_steps, hipStream_t st) {
+  const int64_t B = t->cfg.batch_size, H = t->cfg.hidden_dim, NH = n_hidden(t->cfg);
+  for (int64_t i = 0; i < n_steps; ++i) {
+    DeepStep s;
+    memset(&s, 0, sizeof(s));
+    s.rows = a.rows, s.n_rows = a.n_rows, s.row_stride = a.row_stride, s.idx_mode = a.idx_mode;
+    s.idx = a.idx ? a.idx + i * B : nullptr;
+    s.drop_keep = a.drop_keep ? a.drop_keep + i * NH * B * H : nullptr;
+    s.losses_out = a.losses_out ? a.losses_out + i * 3 : nullptr;
+    s.step = a.base_step + i;
+    s.coef = make_adam_coef(t->cfg.adam_beta1, t->cfg.adam_beta2, t->cfg.adam_eps, a.lr_q, a.lr_v, a.lr_a_base,
+                            t->cfg.cosine_t_max, s.step + 1);
+    HIP_TRY(deep_step(t->deep, s, st, t->timing ? t->ev : nullptr));
+    if (t->timing) {
+      HIP_TRY(hipEventRecord(t->ev[4], st));
+      HIP_TRY(hipEventSynchronize(t->ev[4]));
+      for (int k = 0; k < 3; ++k) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, t->ev[k], t->ev[k + 1]));
+        t->t_acc[k] += ms;
+      }
+      float ems = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ems, t->ev[3], t->ev[4]));
+      t->t_empty += ems;
+      t->t_n++;
+    } else {
+      HIP_TRY(t->throttle.queued(3, st));
+    }
+  }
+  return 0;
+}
+
 static int run_steps(iqlhip_trainer *t, const DevArgs &args_in, int64_t n_steps, int graph_unroll,
                      hipStream_t st) {
+  if (t->deep) return run_steps_deep(t, args_in, n_steps, st);
   if (t->group) group_invalidate(t->group);  // this call rewrites the member's slot of the group's arguments
   if (!(t->D.prefetch && t->dev_args_valid && !t->timing && continues(t->dev_args, args_in))) {
     HIP_TRY(push_args(t, args_in, n_steps, st));
@@ -997,6 +1087,9 @@ extern "C" int iqlhip_group_create(iqlhip_group **out, iqlhip_trainer *const *tr
   if (n < 1 || n > IQLHIP_MAX_GROUP) return fail(IQLHIP_ERR_INVALID, "group size %d: 1..%d", n, IQLHIP_MAX_GROUP);
   for (int k = 0; k < n; ++k) {
     if (!trainers[k]) return fail(IQLHIP_ERR_INVALID, "null trainer");
+    if (trainers[k]->deep)
+      return fail(IQLHIP_ERR_UNSUPPORTED, "seed groups run on the tuned step only (n_hidden = 2, hidden_dim 64 / 128 / "
+                  "256); step trainers of other shapes one by one");
     if (trainers[k]->group) return fail(IQLHIP_ERR_INVALID, "trainer %d already belongs to a group", k);
     for (int j = 0; j < k; ++j)
       if (trainers[j] == trainers[k]) return fail(IQLHIP_ERR_INVALID, "trainer %d listed twice", k);
@@ -1273,6 +1366,11 @@ extern "C" int iqlhip_forward(iqlhip_trainer *t, int32_t which, const float *s, 
   if (n <= 0) return fail(IQLHIP_ERR_INVALID, "n must be positive");
   if ((which == 0 || which == 3) && !a) return fail(IQLHIP_ERR_INVALID, "Q forward needs actions");
   hipStream_t st = (hipStream_t)stream;
+  if (t->deep) {
+    if (which < 0 || which > 3) return fail(IQLHIP_ERR_INVALID, "which must be 0..3");
+    HIP_TRY(deep_infer(t->deep, which, s, a, n, out, st));
+    return 0;
+  }
   const int E = t->D.E;
   FwdNet N;
   switch (which) {
@@ -1325,6 +1423,7 @@ extern "C" int iqlhip_mlp_forward(const iqlhip_mlp_desc *d, const float *x, int6
 // Diagnostic: attach a device buffer [3][512][8][2] u64 for IQL_STAMPS builds.
 extern "C" int iqlhip_trainer_set_debug(iqlhip_trainer *t, void *buf) {
   if (!t) return fail(IQLHIP_ERR_INVALID, "null trainer");
+  if (t->deep) return fail(IQLHIP_ERR_UNSUPPORTED, "no stamps in the general step");
   t->D.dbg = reinterpret_cast<unsigned long long *>(buf);
   HIP_TRY(hipMemcpy(t->ddesc, &t->D, sizeof(TrainerDesc), hipMemcpyHostToDevice));
   if (t->gexec) {

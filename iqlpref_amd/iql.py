@@ -472,10 +472,11 @@ class ValueFunction(nn.Module):
 # --------------------------------------------------------------------------- #
 # trainer (ref:546-688)
 # --------------------------------------------------------------------------- #
-def _three_linears(mlp: MLP, what: str) -> List[nn.Linear]:
+def _linears(mlp: MLP, what: str) -> List[nn.Linear]:
+    """The Linear layers of one network (n_hidden + 1 of them, ref:417-449)."""
     lin = mlp.linears()
-    if len(lin) != 3:
-        raise NotImplementedError(f"{what}: the HIP step is built for n_hidden=2 (got {len(lin) - 1})")
+    if not 2 <= len(lin) <= _lib.MAX_HIDDEN + 1:
+        raise NotImplementedError(f"{what}: n_hidden must be in 1..{_lib.MAX_HIDDEN} (got {len(lin) - 1})")
     if mlp._hidden_act != 0:
         raise NotImplementedError(f"{what}: hidden activation must be ReLU")
     return lin
@@ -538,15 +539,18 @@ class ImplicitQLearning:
         self._deterministic = isinstance(actor, DeterministicPolicy)
         crit = q_network.critics()
         self._n_critics = E = len(crit)
-        self._nets = [(f"q{e + 1}", _three_linears(c, f"TwinQ.q{e + 1}")) for e, c in enumerate(crit)]
-        self._nets += [("v", _three_linears(v_network.v, "ValueFunction")),
-                       ("actor", _three_linears(actor.net, "actor"))]
+        self._nets = [(f"q{e + 1}", _linears(c, f"TwinQ.q{e + 1}")) for e, c in enumerate(crit)]
+        self._nets += [("v", _linears(v_network.v, "ValueFunction")),
+                       ("actor", _linears(actor.net, "actor"))]
         self._state_dim = self._nets[E][1][0].in_features
-        self._action_dim = self._nets[E + 1][1][2].out_features
+        self._action_dim = self._nets[E + 1][1][-1].out_features
         self._hidden = self._nets[E][1][0].out_features
+        self._n_hidden = len(self._nets[E][1]) - 1
         for _, lin in self._nets:
-            if lin[0].out_features != self._hidden or lin[1].in_features != self._hidden or \
-                    lin[1].out_features != self._hidden or lin[2].in_features != self._hidden:
+            if len(lin) != self._n_hidden + 1:
+                raise NotImplementedError("all networks must have the same number of hidden layers")
+            if any(l.out_features != self._hidden for l in lin[:-1]) or \
+                    any(l.in_features != self._hidden for l in lin[1:]):
                 raise NotImplementedError("all hidden layers must share one width")
         if self._nets[0][1][0].in_features != self._state_dim + self._action_dim:
             raise ValueError("TwinQ input width must be state_dim + action_dim")
@@ -585,6 +589,7 @@ class ImplicitQLearning:
         c.seed = self._seed
         c.n_critics = self._n_critics
         c.polyak_form = self._polyak_form
+        c.n_hidden = self._n_hidden
         return c
 
     def _tensor_list(self) -> List[nn.Parameter]:
@@ -630,7 +635,7 @@ class ImplicitQLearning:
             for l in mlp.linears():
                 tl += [l.weight, l.bias]
         with torch.no_grad():
-            for p, o in zip(tl, self._offsets[:6 * self._n_critics]):
+            for p, o in zip(tl, self._offsets[:2 * (self._n_hidden + 1) * self._n_critics]):
                 view = self._target[o:o + p.numel()].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
@@ -685,6 +690,14 @@ class ImplicitQLearning:
             self._destroy_handle()
         except Exception:
             pass
+
+    def step_kind(self, batch_size: int) -> str:
+        """"tuned" (the three-kernel step of csrc/iql_step.hip: n_hidden = 2, hidden_dim 64 / 128 / 256) or
+        "general" (the layer-wise step of csrc/iql_deep.hip: every other depth / width)."""
+        self._ensure_handle(batch_size)
+        kind = C.c_int32()
+        check(self._lib.iqlhip_trainer_step_kind(self._handle, C.byref(kind)))
+        return "general" if kind.value else "tuned"
 
     def sync_weights(self):
         """Call after writing parameters from outside (the compute-precision copies

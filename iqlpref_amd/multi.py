@@ -52,8 +52,14 @@ def _slice_streams(lib, dev, n_slices: int):
 
 
 def _shape_key(t: ImplicitQLearning):
-    return (t._state_dim, t._action_dim, t._hidden, t._precision, t._deterministic, t._n_critics,
+    return (t._state_dim, t._action_dim, t._hidden, t._n_hidden, t._precision, t._deterministic, t._n_critics,
             bool(t._dropout))
+
+
+def _on_tuned_step(t: ImplicitQLearning) -> bool:
+    """Group launches exist for the tuned three-kernel step only (include/iqlhip.h, shape envelope);
+    trainers of other shapes (n_hidden != 2, other widths) are stepped one by one, each on its stream."""
+    return t._n_hidden == 2 and t._hidden in (64, 128, 256)
 
 
 class SeedGroup:
@@ -66,14 +72,16 @@ class SeedGroup:
             raise ValueError("all trainers of a SeedGroup must live on one device")
         if len({id(t) for t in trainers}) != len(trainers):
             raise ValueError("a trainer may appear only once in a SeedGroup")
-        one_shape = len({_shape_key(t) for t in trainers}) == 1 and len(trainers) <= _lib.MAX_GROUP
+        one_shape = len({_shape_key(t) for t in trainers}) == 1 and len(trainers) <= _lib.MAX_GROUP and \
+            all(_on_tuned_step(t) for t in trainers)
         if mode is None:  # the fastest arrangement measured for the shape at hand
             mode = ("split" if len(trainers) >= 2 else "group") if one_shape else "streams"
         if mode not in ("group", "streams", "split"):
             raise ValueError("mode must be 'group', 'streams' or 'split'")
         if mode in ("group", "split") and not one_shape:
             raise ValueError(f"mode='group' needs at most {_lib.MAX_GROUP} trainers of one shape (dims, hidden, "
-                             "precision, policy kind, critics, dropout on/off)")
+                             "precision, policy kind, critics, dropout on/off) that runs on the tuned step "
+                             "(n_hidden = 2, hidden_dim 64 / 128 / 256)")
         self.mode = mode
         self.trainers: List[ImplicitQLearning] = list(trainers)
         self._dev = next(iter(devs))

@@ -121,17 +121,17 @@ def adam_state(opt, module):
 
 def run_trajectory(ref, *, s_dim, a_dim, hidden, batch, n_rows, k_steps, seed,
                    beta, iql_tau, discount, tau, deterministic, dropout, max_steps,
-                   fp32, reward_kind, snap_steps=(), ckpt_at=None):
+                   fp32, reward_kind, snap_steps=(), ckpt_at=None, n_hidden=2):
     rng = np.random.default_rng(seed)
     data = synth_dataset(rng, n_rows, s_dim, a_dim, reward_kind)
     buf = ref.ReplayBuffer(s_dim, a_dim, n_rows + 7, "cpu")
     buf.load_d4rl_dataset(data)
 
     torch.manual_seed(seed)
-    q = ref.TwinQ(s_dim, a_dim, hidden_dim=hidden)
-    v = ref.ValueFunction(s_dim, hidden_dim=hidden)
+    q = ref.TwinQ(s_dim, a_dim, hidden_dim=hidden, n_hidden=n_hidden)
+    v = ref.ValueFunction(s_dim, hidden_dim=hidden, n_hidden=n_hidden)
     pol_cls = ref.DeterministicPolicy if deterministic else ref.GaussianPolicy
-    actor = pol_cls(s_dim, a_dim, 1.0, hidden_dim=hidden, dropout=dropout)
+    actor = pol_cls(s_dim, a_dim, 1.0, hidden_dim=hidden, n_hidden=n_hidden, dropout=dropout)
     if not deterministic:
         with torch.no_grad():  # non-trivial log_std so its gradient path is exercised
             actor.log_std.copy_(torch.linspace(-0.5, 0.3, a_dim))
@@ -230,11 +230,11 @@ def run_trajectory(ref, *, s_dim, a_dim, hidden, batch, n_rows, k_steps, seed,
     out.update(flat("final/v_adam", adam_state(vo, v)))
     out.update(flat("final/actor_adam", adam_state(ao, actor)))
     if masks:
-        m = np.stack(masks).reshape(k_steps, 2, batch, hidden)
+        m = np.stack(masks).reshape(k_steps, n_hidden, batch, hidden)
         out["dropout_keep"] = np.packbits(m, axis=-1)
     out["hyper"] = np.asarray(
         [s_dim, a_dim, hidden, batch, n_rows, k_steps, beta, iql_tau, discount, tau,
-         float(deterministic), -1.0 if dropout is None else dropout, max_steps],
+         float(deterministic), -1.0 if dropout is None else dropout, max_steps, n_hidden],
         dtype=np.float64)
     sd = trainer.state_dict()
     out["state_dict_keys"] = np.asarray(sorted(sd.keys()))
@@ -242,6 +242,24 @@ def run_trajectory(ref, *, s_dim, a_dim, hidden, batch, n_rows, k_steps, seed,
     out["qf_keys"] = np.asarray(list(sd["qf"].keys()))
     out["vf_keys"] = np.asarray(list(sd["vf"].keys()))
     return out
+
+
+# Depths and widths away from the default n_hidden = 2 / hidden_dim 256 (ref:417-449 MLP, :458-459, 519, 538):
+# what the general layer-wise step (csrc/iql_deep.hip) runs.  Small on purpose: full parameter sets are kept.
+SHAPES = {
+    # three hidden layers of a width that is no multiple of 32, Gaussian policy, antmaze hyper-parameters
+    "traj_deep3_w96": dict(s_dim=29, a_dim=8, hidden=96, n_hidden=3, batch=64, n_rows=1000, k_steps=8, seed=11,
+                           beta=10.0, iql_tau=0.9, discount=0.99, tau=0.005, deterministic=False, dropout=None,
+                           max_steps=1000, reward_kind="sparse"),
+    # ONE hidden layer of a width that is no multiple of 16, pen shapes with actor dropout
+    "traj_shallow1_w40_drop": dict(s_dim=45, a_dim=24, hidden=40, n_hidden=1, batch=32, n_rows=500, k_steps=6, seed=12,
+                                   beta=3.0, iql_tau=0.8, discount=0.99, tau=0.005, deterministic=False, dropout=0.1,
+                                   max_steps=50, reward_kind="normal"),
+    # four hidden layers, deterministic policy with dropout in every one of them, halfcheetah shapes
+    "traj_deep4_w72_det": dict(s_dim=17, a_dim=6, hidden=72, n_hidden=4, batch=48, n_rows=700, k_steps=6, seed=13,
+                               beta=3.0, iql_tau=0.7, discount=0.99, tau=0.005, deterministic=True, dropout=0.2,
+                               max_steps=100, reward_kind="normal"),
+}
 
 
 def big_summary(ref, fp32):
@@ -986,7 +1004,7 @@ def main():
     ap.add_argument("--checkpoint-compat", default=None,
                     help="only write checkpoint_compat.npz from this checkpoint of our trainer")
     ap.add_argument("--only", default=None,
-                    help="comma-separated subset: small, h256, big, per_op, dataset_ops, eval, custom, train, long, resume")
+                    help="comma-separated subset: small, h256, big, per_op, dataset_ops, eval, custom, train, long, resume, shapes")
     args = ap.parse_args()
     torch.set_num_threads(1)  # fixed summation order for the captured vectors
     ref = import_reference(args.ref)
@@ -1008,6 +1026,10 @@ def main():
         for name in LONG:
             for fp32 in (True, False):
                 save(f"{name}_{'fp32' if fp32 else 'bf16'}.npz", long_regen(ref, name, fp32))
+    if want("shapes"):
+        for name, cfg in SHAPES.items():
+            for fp32 in (True, False):
+                save(f"{name}_{'fp32' if fp32 else 'bf16'}.npz", run_trajectory(ref, fp32=fp32, **cfg))
     if want("big"):
         for name in BIG:
             for fp32 in (True, False):

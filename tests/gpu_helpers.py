@@ -10,11 +10,12 @@ DEV = "cuda:0"
 def make_nets(hyper, nets, device=DEV):
     qf_p, vf_p, actor_p = nets
     S, A, H = hyper["s_dim"], hyper["a_dim"], hyper["hidden"]
-    E = hyper.get("n_critics", 2)
-    q = ia.TwinQ(S, A, hidden_dim=H) if E == 2 else ia.EnsembleQ(S, A, hidden_dim=H, n_critics=E)
-    v = ia.ValueFunction(S, hidden_dim=H)
+    E, NH = hyper.get("n_critics", 2), hyper.get("n_hidden", 2)
+    q = ia.TwinQ(S, A, hidden_dim=H, n_hidden=NH) if E == 2 else \
+        ia.EnsembleQ(S, A, hidden_dim=H, n_hidden=NH, n_critics=E)
+    v = ia.ValueFunction(S, hidden_dim=H, n_hidden=NH)
     cls = ia.DeterministicPolicy if hyper["deterministic"] else ia.GaussianPolicy
-    actor = cls(S, A, 1.0, hidden_dim=H, dropout=hyper["dropout"])
+    actor = cls(S, A, 1.0, hidden_dim=H, n_hidden=NH, dropout=hyper["dropout"])
     for mod, params in ((q, qf_p), (v, vf_p), (actor, actor_p)):
         sd = {k: torch.from_numpy(np.asarray(a)) for k, a in params.items()}
         missing = mod.load_state_dict(sd, strict=True)

@@ -10,6 +10,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRAJ = ["traj_antmaze", "traj_cheetah_det", "traj_pen_dropout", "traj_antmaze_h256"]
 # BASELINE configs 1 / 3 and config 5's batch at H = 256 (initial parameters and data rebuilt from the seed)
 TRAJ_BIG = ["traj_cheetah_h256", "traj_pen_h256", "traj_antmaze_b1024"]
+# depths / widths away from the default (make_fixtures.SHAPES): the general layer-wise step
+TRAJ_SHAPES = ["traj_deep3_w96", "traj_shallow1_w40_drop", "traj_deep4_w72_det"]
 
 
 def synth_dataset(rng, n, s_dim, a_dim, reward="normal"):
@@ -98,7 +100,8 @@ def load_traj(name, mode):
         s_dim=int(h[0]), a_dim=int(h[1]), hidden=int(h[2]), batch=int(h[3]),
         n_rows=int(h[4]), k_steps=int(h[5]), beta=float(h[6]), iql_tau=float(h[7]),
         discount=float(h[8]), tau=float(h[9]), deterministic=bool(h[10]),
-        dropout=None if h[11] < 0 else float(h[11]), max_steps=int(h[12]))
+        dropout=None if h[11] < 0 else float(h[11]), max_steps=int(h[12]),
+        n_hidden=int(h[13]) if len(h) > 13 else 2)
     if "regen_seed" in d.files:
         data, nets = regen_inputs(d)
         return d, hyper, data, nets
@@ -111,7 +114,7 @@ def keep_masks(d, hyper, t):
     if hyper["dropout"] is None:
         return None
     m = np.unpackbits(d["dropout_keep"][t], axis=-1)[..., :hyper["hidden"]].astype(bool)
-    return [m[0], m[1]]
+    return [m[l] for l in range(m.shape[0])]
 
 
 def make_oracle(hyper, nets, mode):

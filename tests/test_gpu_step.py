@@ -89,6 +89,14 @@ TOL = {
 # this round's run): movement vs the oracle <= 0.0004, vs the reference's golden <= 0.0016.
 BF16_DELTA_ORACLE = 0.005
 BF16_DELTA_GOLDEN = 0.01
+# three / four hidden layers (the general step, TRAJ_SHAPES) AGAINST THE ORACLE: one bf16 rounding tie in a
+# gradient entry of step 1 that falls the other way under numpy's summation order, amplified by Adam's sign-like
+# early steps -- the oracle itself leaves the reference's trajectory there (traj_deep3_w96: q_loss 6.5e-6 off at
+# step 2, 4.7e-4 at step 8; exact at step 1), while the HIP step stays on it (losses 1.1e-7, movement of every
+# tensor 0.0000 relative L2 from the reference's; gpurun_out/deep4_diag.txt).  Bounds = 5 x measured against the
+# oracle (movement 0.0125, moments 1.2e-2); against the reference's own arrays the ordinary bounds hold.
+BF16_DELTA_DEEP = 0.06
+MOMENT_TOL_DEEP = (0.06, 0.06)
 # Adam moments, largest error relative to the tensor's largest entry: (fp32, bf16) -- the bf16 figures
 # are ~5 x the measured ones; at H = 256 one relu'(z) falling the other way under another summation
 # order moves isolated entries by a sample's share (see tests/test_oracle_golden.py), so there the
@@ -102,13 +110,15 @@ def _delta_rel(final, init, want_final):
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
-@pytest.mark.parametrize("name", helpers.TRAJ + helpers.TRAJ_BIG)
+@pytest.mark.parametrize("name", helpers.TRAJ + helpers.TRAJ_BIG + helpers.TRAJ_SHAPES)
 def test_trajectory_parity(gh, name, mode):
     """K steps with the reference's injected indices (and dropout masks) vs the oracle AND the
     reference's own trajectory.  TRAJ_BIG = BASELINE configs 1 / 3 and config 5's batch at H = 256."""
     d, hyper, data, nets = helpers.load_traj(name, mode)
     K, B = hyper["k_steps"], hyper["batch"]
     tr = gh.make_trainer(hyper, nets, mode)
+    if not os.environ.get("IQLHIP_FORCE_GENERAL"):  # (set: every shape through the general step)
+        assert tr.step_kind(B) == ("general" if name in helpers.TRAJ_SHAPES else "tuned")
     buf = gh.make_buffer(hyper, data)
     idx = torch.from_numpy(d["indices"]).to(gh.DEV)
     losses = tr.train_steps(buf, K, B, indices=idx, dropout_keep=_drop_tensor(d, hyper, gh),
@@ -136,6 +146,15 @@ def test_trajectory_parity(gh, name, mode):
             wantg, gotg = helpers.golden_param(d, f"final/{net}/{k}", v)
             assert wantg is not None
             wantg = wantg.reshape(gotg.shape)
+            if mode == "fp32" and not big and name in helpers.TRAJ_SHAPES:
+                # as below for H = 256: a gradient entry that is pure summation noise (dropout zeroes whole
+                # units) takes sign-like Adam steps -- traj_shallow1_w40_drop: 1 of 2,760 entries of a critic's
+                # first layer, 7e-6 from the reference's; the oracle shows the same entry 5e-6 away
+                # (test_oracle_golden.py).  All but 0.1 % of a tensor within the bound, none beyond K lr.
+                for what, a, b in (("oracle", v, opar[k]), ("golden", gotg, wantg)):
+                    diff = np.abs(a - b)
+                    assert (diff > tol["po"]).mean() < 1e-3 and diff.max() < K * 3e-4 * 1.01, (net, k, what, diff.max())
+                continue
             if mode == "fp32" and not big:
                 np.testing.assert_allclose(v, opar[k], atol=tol["po"], rtol=0, err_msg=f"{net}/{k} vs oracle")
                 np.testing.assert_allclose(gotg, wantg, atol=tol["pg"], rtol=0, err_msg=f"{net}/{k} vs golden")
@@ -159,7 +178,9 @@ def test_trajectory_parity(gh, name, mode):
                 continue
             rel = _delta_rel(v, np.asarray(init[k]), opar[k])
             _diag(f"{name} {net}/{k} delta rel vs oracle {rel:.4f}")
-            assert rel < BF16_DELTA_ORACLE, f"{net}/{k}: movement differs from the oracle's by {rel:.4f} (rel. L2)"
+            deep = name in helpers.TRAJ_SHAPES and hyper["n_hidden"] > 2
+            assert rel < (BF16_DELTA_DEEP if deep else BF16_DELTA_ORACLE), \
+                f"{net}/{k}: movement differs from the oracle's by {rel:.4f} (rel. L2)"
             # (large tensors are stored as every 37th element: the movement of that sample)
             initg = np.asarray(init[k]).reshape(-1)[::37] if wantg.size != v.size else np.asarray(init[k])
             relg = _delta_rel(gotg, initg.reshape(gotg.shape), wantg)
@@ -167,6 +188,8 @@ def test_trajectory_parity(gh, name, mode):
             assert relg < BF16_DELTA_GOLDEN, f"{net}/{k}: movement vs the reference {relg:.4f}"
     # Adam moments (exp_avg = EMA of the gradients: pins the backward pass)
     t1, t2 = MOMENT_TOL[mode]
+    if mode == "bf16" and name in helpers.TRAJ_SHAPES and hyper["n_hidden"] > 2:
+        t1, t2 = MOMENT_TOL_DEEP
     for which, opt, mod in (("q", tr.q_optimizer, tr.qf), ("v", tr.v_optimizer, tr.vf),
                             ("actor", tr.actor_optimizer, tr.actor)):
         for (pname, p) in mod.named_parameters():

@@ -60,9 +60,22 @@ def test_arena_layout_and_step_cost_match_survey():
     b, f = ctypes.c_double(), ctypes.c_double()
     assert lib.iqlhip_step_cost(ctypes.byref(c), ctypes.byref(b), ctypes.byref(f)) == 0
     assert b.value == 10_908_272
-    c.hidden_dim = 100
-    assert lib.iqlhip_arena_layout(ctypes.byref(c), None, None, None) == _lib.ERR_UNSUPPORTED
-    assert b"hidden_dim" in lib.iqlhip_last_error()
+    # any depth 1..6 and width 1..1024 (ref:417-449 MLP): 2 (n_hidden + 1) tensors per network, then log_std
+    c.hidden_dim, c.n_hidden = 100, 3
+    assert lib.iqlhip_arena_layout(ctypes.byref(c), ctypes.byref(offs), ctypes.byref(n_p), ctypes.byref(n_t)) == 0
+    sizes = []
+    for in_dim, out in ((37, 1), (37, 1), (29, 1), (29, 8)):
+        sizes += [100 * in_dim, 100, 100 * 100, 100, 100 * 100, 100, out * 100, out]
+    sizes.append(8)
+    for k in range(33):
+        assert offs[k] % 32 == 0 and (k == 0 or offs[k] >= offs[k - 1] + sizes[k - 1])
+    assert n_p.value == offs[32] + 8 and offs[33] == -1 and n_t.value <= offs[16]
+    assert lib.iqlhip_step_cost(ctypes.byref(c), ctypes.byref(b), ctypes.byref(f)) == 0
+    assert b.value == 4 * 256 * (2 * 29 + 8 + 2) + 32 * sum(sizes) + 8 * sum(sizes[:16])
+    for hd, nh, word in ((2000, 2, b"hidden_dim"), (256, 7, b"n_hidden")):
+        c.hidden_dim, c.n_hidden = hd, nh
+        assert lib.iqlhip_arena_layout(ctypes.byref(c), None, None, None) == _lib.ERR_UNSUPPORTED
+        assert word in lib.iqlhip_last_error()
 
 
 @pytest.mark.parametrize("seed", range(6))
