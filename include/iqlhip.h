@@ -54,7 +54,8 @@ const char *iqlhip_build_tag(void);
 /*             the tuned three-kernel step; every other shape on the general   */
 /*             layer-wise step (csrc/iql_deep.hip: same arithmetic, plain      */
 /*             launches only, no seed groups);                                 */
-/*   MLP fwd   1..8 layers, every width in [1, 256];                           */
+/*   MLP fwd   1..8 layers, every width in [1, 1024] (beyond 256: a plain      */
+/*             one-wave-per-16-rows variant);                                  */
 /*   CVaR      1 <= n_tail <= S <= 2400;                                       */
 /*   PT        embd_dim 64, ONE GPT-2 block, num_heads a power of two <= 16,   */
 /*             inter_dim a multiple of 256 up to 1024, state_dim + action_dim  */
@@ -298,7 +299,7 @@ int iqlhip_forward(iqlhip_trainer *t, int32_t which, const float *s, const float
 #define IQLHIP_MLP_MAX_LAYERS 8
 typedef struct {
   int32_t n_layers;                          /* Linear layers, 1..8                */
-  int32_t dims[IQLHIP_MLP_MAX_LAYERS + 1];   /* in, hidden..., out; each <= 256     */
+  int32_t dims[IQLHIP_MLP_MAX_LAYERS + 1];   /* in, hidden..., out; each <= 1024    */
   const float *weights[IQLHIP_MLP_MAX_LAYERS]; /* device fp32                      */
   const float *biases[IQLHIP_MLP_MAX_LAYERS];  /* device fp32 [out]                */
   int32_t w_in_out;   /* 0: W[out][in] (torch nn.Linear); 1: W[in][out] (x @ W)  */

@@ -1406,8 +1406,8 @@ extern "C" int iqlhip_mlp_forward(const iqlhip_mlp_desc *d, const float *x, int6
   if (d->n_layers < 1 || d->n_layers > IQLHIP_MLP_MAX_LAYERS)
     return fail(IQLHIP_ERR_INVALID, "n_layers must be in [1, %d]", IQLHIP_MLP_MAX_LAYERS);
   for (int i = 0; i <= d->n_layers; ++i)
-    if (d->dims[i] <= 0 || d->dims[i] > 256)
-      return fail(IQLHIP_ERR_UNSUPPORTED, "layer width %d outside [1, 256]", d->dims[i]);
+    if (d->dims[i] <= 0 || d->dims[i] > 1024)
+      return fail(IQLHIP_ERR_UNSUPPORTED, "layer width %d outside [1, 1024]", d->dims[i]);
   for (int i = 0; i < d->n_layers; ++i)
     if (!d->weights[i] || !d->biases[i]) return fail(IQLHIP_ERR_INVALID, "null weight pointer");
   for (int a : {d->hidden_act, d->out_act})

@@ -3,12 +3,12 @@
 // (ref:417-449 MLP, :452-543 the networks; ref:581-662 the step).  Same arithmetic (step_math.h),
 // same arenas, same index / dropout streams; three plain launches per step:
 //
-//   kd_forward   (2E+3 evaluations) x B/16 slabs, ONE wave each: the slab's 16 transitions gathered
+//   kd_forward   (2E+3 evaluations) x B/16 slabs, four waves each: the slab's 16 transitions gathered
 //                from the packed replay rows, then every Linear on MFMA -- A fragments from a
 //                row-major LDS image of the previous layer's output, B fragments straight from the
 //                row-major compute copy W[n][k] in L2 -- with the hidden activations of the trained
 //                nets stored feature-major for the other two kernels.
-//   kd_backward  (E+2 trained nets) x B/16 slabs, one wave each: loss terms, d(out), then
+//   kd_backward  (E+2 trained nets) x B/16 slabs, four waves each: loss terms, d(out), then
 //                dZ_{l-1} = (dZ_l W_l) * relu' layer by layer (B fragments from the transposed copies
 //                Wt[k][n]), deltas stored feature-major; per-slab loss partial sums.
 //   kd_update    64 x 64 tiles of every weight matrix: dW = dZ^T X (K = batch, both operands
@@ -94,30 +94,39 @@ __device__ __forceinline__ void deep_keep4(const DeepDesc &D, const DeepStep &A,
   }
 }
 
-// One 16 x 16 output tile: acc = A[16][K] (LDS, row-major, row stride ldw) x B[16][K]^T (global, row
-// stride ldb); K = nk MFMA steps.  Four steps of operands are requested before the first MFMA.
+// Two 16 x 16 output tiles that share their A operand: acc_j = A[16][K] (LDS, row-major) x B_j[16][K]^T
+// (global, K-contiguous rows); K = nk MFMA steps.  Four steps of operands (8 global + 4 LDS fragments)
+// are requested before the first MFMA of a chunk.
 template <bool BF16>
-__device__ __forceinline__ f32x4 tile_mma(const typename Prec<BF16>::T *arow, const typename Prec<BF16>::T *brow,
-                                          int nk) {
+__device__ __forceinline__ void tile_mma2(const typename Prec<BF16>::T *arow, const typename Prec<BF16>::T *brow0,
+                                          const typename Prec<BF16>::T *brow1, int nk, f32x4 &acc0, f32x4 &acc1) {
   using P = Prec<BF16>;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
   int ks = 0;
   for (; ks + 4 <= nk; ks += 4) {
-    uint4 b[4], a[4];
+    uint4 b0[4], b1[4], a[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) b[u] = ldg16(brow + (size_t)(ks + u) * P::KM);
+    for (int u = 0; u < 4; ++u) {
+      b0[u] = ldg16(brow0 + (size_t)(ks + u) * P::KM);
+      b1[u] = ldg16(brow1 + (size_t)(ks + u) * P::KM);
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const uint4 *>(arow + (size_t)(ks + u) * P::KM);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) P::mma(a[u], b[u], acc);
+    for (int u = 0; u < 4; ++u) {
+      P::mma(a[u], b0[u], acc0);
+      P::mma(a[u], b1[u], acc1);
+    }
   }
   for (; ks < nk; ++ks) {
-    const uint4 b = ldg16(brow + (size_t)ks * P::KM);
+    const uint4 b0 = ldg16(brow0 + (size_t)ks * P::KM), b1 = ldg16(brow1 + (size_t)ks * P::KM);
     const uint4 a = *reinterpret_cast<const uint4 *>(arow + (size_t)ks * P::KM);
-    P::mma(a, b, acc);
+    P::mma(a, b0, acc0);
+    P::mma(a, b1, acc1);
   }
-  return acc;
 }
+
+constexpr int DEEP_THREADS = 256;  // four waves share a slab's LDS images; wave w owns the tile pairs w, w + 4, ...
 
 // All Linear layers of one evaluation for the 16 rows whose inputs sit in `in` (LDS, row-major,
 // zero padded to the first layer's Kpad).  hidden(l, col, a[4]) receives the activations behind
@@ -128,40 +137,47 @@ __device__ __forceinline__ void deep_layers(const DeepDesc &D, const DeepEval &N
                                             Hidden hidden, Final final) {
   using P = Prec<BF16>;
   using T = typename P::T;
-  const int lane = threadIdx.x, r16 = lane & 15, q = lane >> 4, ldw = D.lds_w, NL = D.NL;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4, ldw = D.lds_w, NL = D.NL;
   for (int l = 0; l < NL; ++l) {
     const DeepLin &Lk = N.lin[l];
-    const int Kpad = Lk.Kpad, Npad = Lk.Npad, Nn = Lk.N, nk = Kpad / P::KM;
+    const int Kpad = Lk.Kpad, ntile = Lk.Npad / 16, Nn = Lk.N, nk = Kpad / P::KM;
     const T *W = reinterpret_cast<const T *>(Lk.w);
     const float *bias = Lk.b;
     const bool last = l == NL - 1;
     const T *arow = in + (size_t)r16 * ldw + q * P::EPV;
-    for (int nt = 0; nt < Npad / 16; ++nt) {
-      const int col = nt * 16 + r16;
-      const f32x4 acc = tile_mma<BF16>(arow, W + (size_t)col * Kpad + q * P::EPV, nk);
-      // nn.Linear under autocast: bf16 inputs, weights AND bias, fp32 accumulation, bf16 result
-      const float bv = col < Nn ? P::round(ldg(bias + col)) : 0.f;
-      float z[4];
+    for (int nt = 2 * wave; nt < ntile; nt += 2 * (DEEP_THREADS / 64)) {
+      const bool two = nt + 1 < ntile;  // (the output layer may have a single tile: its twin is computed and dropped)
+      const int col0 = nt * 16 + r16, col1 = two ? col0 + 16 : col0;
+      f32x4 acc[2];
+      tile_mma2<BF16>(arow, W + (size_t)col0 * Kpad + q * P::EPV, W + (size_t)col1 * Kpad + q * P::EPV, nk, acc[0], acc[1]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) z[i] = P::round(acc[i] + bv);
-      if (!last) {
+      for (int j = 0; j < 2; ++j) {
+        if (j == 1 && !two) break;
+        const int col = j ? col1 : col0;
+        // nn.Linear under autocast: bf16 inputs, weights AND bias, fp32 accumulation, bf16 result
+        const float bv = col < Nn ? P::round(ldg(bias + col)) : 0.f;
+        float z[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) z[i] = fmaxf(z[i], 0.f);
-        if (dropout) {
-          bool keep[4];
-          deep_keep4(D, *A, l, rowblk + q, col, keep);
+        for (int i = 0; i < 4; ++i) z[i] = P::round(acc[j][i] + bv);
+        if (!last) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) z[i] = P::round(z[i] * (keep[i] ? D.drop_scale : 0.f));
+          for (int i = 0; i < 4; ++i) z[i] = fmaxf(z[i], 0.f);
+          if (dropout) {
+            bool keep[4];
+            deep_keep4(D, *A, l, rowblk + q, col, keep);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[i] = P::round(z[i] * (keep[i] ? D.drop_scale : 0.f));
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) out[(size_t)(4 * q + i) * ldw + col] = P::from_f32(z[i]);
+          hidden(l, col, z);
+        } else {
+          if (N.tanh_out) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[i] = P::round(tanhf(z[i]));
+          }
+          final(col, z);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) out[(size_t)(4 * q + i) * ldw + col] = P::from_f32(z[i]);
-        hidden(l, col, z);
-      } else {
-        if (N.tanh_out) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) z[i] = P::round(tanhf(z[i]));
-        }
-        final(col, z);
       }
     }
     __syncthreads();
@@ -182,25 +198,25 @@ __device__ __forceinline__ int64_t deep_row_index(const DeepDesc &D, const DeepS
 }
 
 // ------------------------------------------------------------------------
-// kd_forward: grid (B/16, 2E+3), one wave.
+// kd_forward: grid (B/16, 2E+3), four waves.
 // ------------------------------------------------------------------------
 template <bool BF16>
-__global__ __launch_bounds__(64) void kd_forward(const DeepDesc *__restrict__ Dp, const DeepStep A) {
+__global__ __launch_bounds__(DEEP_THREADS) void kd_forward(const DeepDesc *__restrict__ Dp, const DeepStep A) {
   using P = Prec<BF16>;
   using T = typename P::T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const DeepDesc &D = *Dp;
   const DeepEval &N = D.ev[blockIdx.y];
-  const int lane = threadIdx.x, row0 = blockIdx.x * 16, q = lane >> 4, ldw = D.lds_w, BP = D.BP;
+  const int row0 = blockIdx.x * 16, q = (threadIdx.x & 63) >> 4, ldw = D.lds_w, BP = D.BP;
   T *bufA = reinterpret_cast<T *>(smem), *bufB = bufA + (size_t)16 * ldw;
-  // ---- the slab's inputs: 4 lanes per row ----
+  // ---- the slab's inputs: 16 threads per row ----
   {
-    const int r = lane >> 2, c0 = lane & 3, row = row0 + r;
+    const int r = threadIdx.x >> 4, c0 = threadIdx.x & 15, row = row0 + r;
     const int64_t ix = deep_row_index(D, A, row);
     const float *src = A.rows + (size_t)ix * A.row_stride;
     const int K0 = N.lin[0].Kpad, in_dim = N.in_dim, in_off = N.in_off;
     T *xT = reinterpret_cast<T *>(D.net[0].hT[0]);
-    for (int c = c0; c < K0; c += 4) {
+    for (int c = c0; c < K0; c += 16) {
       const float v = c < in_dim ? ldg(src + in_off + c) : 0.f;
       const T tv = P::from_f32(v);
       bufA[(size_t)r * ldw + c] = tv;
@@ -208,7 +224,7 @@ __global__ __launch_bounds__(64) void kd_forward(const DeepDesc *__restrict__ Dp
     }
     if (N.stage) {  // this evaluation's input is (s | a): reward, done and the fp32 actions ride along
       const int S = D.S, SA = D.S + D.A;
-      for (int c = c0; c < D.A; c += 4) stg(D.actf + (size_t)row * D.A + c, ldg(src + S + c));
+      for (int c = c0; c < D.A; c += 16) stg(D.actf + (size_t)row * D.A + c, ldg(src + S + c));
       if (c0 < 2) stg(D.rd + (size_t)row * 2 + c0, ldg(src + SA + c0));
     }
   }
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(64) void kd_forward(const DeepDesc *__restrict__ Dp
 // Forward on dense inputs (iqlhip_forward): n rows of s [n][S] (and a [n][A]); out[row][col0 + j],
 // row stride out_ld.  Eval mode: no Dropout.
 template <bool BF16>
-__global__ __launch_bounds__(64) void kd_infer(const DeepDesc *__restrict__ Dp, int ev, const float *__restrict__ s,
+__global__ __launch_bounds__(DEEP_THREADS) void kd_infer(const DeepDesc *__restrict__ Dp, int ev, const float *__restrict__ s,
                                                const float *__restrict__ a, int64_t n, float *__restrict__ out,
                                                int out_ld, int col0) {
   using P = Prec<BF16>;
@@ -238,14 +254,14 @@ __global__ __launch_bounds__(64) void kd_infer(const DeepDesc *__restrict__ Dp, 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const DeepDesc &D = *Dp;
   const DeepEval &N = D.ev[ev];
-  const int lane = threadIdx.x, q = lane >> 4, ldw = D.lds_w;
+  const int q = (threadIdx.x & 63) >> 4, ldw = D.lds_w;
   const int64_t row0 = (int64_t)blockIdx.x * 16;
   T *bufA = reinterpret_cast<T *>(smem), *bufB = bufA + (size_t)16 * ldw;
   {
-    const int r = lane >> 2, c0 = lane & 3;
+    const int r = threadIdx.x >> 4, c0 = threadIdx.x & 15;
     const int64_t row = row0 + r < n ? row0 + r : n - 1;
     const int K0 = N.lin[0].Kpad, in_dim = N.in_dim, S = D.S;
-    for (int c = c0; c < K0; c += 4) {
+    for (int c = c0; c < K0; c += 16) {
       float v = 0.f;
       if (c < in_dim) v = c < S ? ldg(s + row * S + c) : ldg(a + row * D.A + (c - S));
       bufA[(size_t)r * ldw + c] = P::from_f32(v);
@@ -267,23 +283,24 @@ __global__ __launch_bounds__(64) void kd_infer(const DeepDesc *__restrict__ Dp, 
 }
 
 // ------------------------------------------------------------------------
-// kd_backward: grid (B/16, E+2), one wave.
+// kd_backward: grid (B/16, E+2), four waves (the loss terms by the first, the layer walk by all).
 // ------------------------------------------------------------------------
 template <bool BF16>
-__global__ __launch_bounds__(64) void kd_backward(const DeepDesc *__restrict__ Dp, const DeepStep A) {
+__global__ __launch_bounds__(DEEP_THREADS) void kd_backward(const DeepDesc *__restrict__ Dp, const DeepStep A) {
   using P = Prec<BF16>;
   using T = typename P::T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const DeepDesc &D = *Dp;
   const int net = blockIdx.y, slab = blockIdx.x, row0 = slab * 16;
   const DeepNet &N = D.net[net];
-  const int lane = threadIdx.x, r16 = lane & 15, q = lane >> 4, ldw = D.lds_w, BP = D.BP, L = D.NL - 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+  const int ldw = D.lds_w, BP = D.BP, L = D.NL - 1;
   T *dzin = reinterpret_cast<T *>(smem), *dzout = dzin + (size_t)16 * ldw;
   // the output layer's delta tile is narrower than one MFMA K step: zero what the GEMM reads beyond it
-  for (int e = lane; e < 16 * ldw; e += 64) dzin[e] = P::from_f32(0.f);
+  for (int e = threadIdx.x; e < 16 * ldw; e += DEEP_THREADS) dzin[e] = P::from_f32(0.f);
   __syncthreads();
   // ---- loss terms and d(loss)/d(out) (ref:581-637) ----
-  {
+  if (wave == 0) {
     const int E = D.E, Aq = D.A, odim = N.N[L];
     const float *outs = D.outs;
     const float fB = (float)D.B;
@@ -331,26 +348,32 @@ __global__ __launch_bounds__(64) void kd_backward(const DeepDesc *__restrict__ D
     T *zp = reinterpret_cast<T *>(N.dzT[l - 1]);
     const int NK = N.NKpad[l], nk = NK / P::KM, Kp = N.Kpad[l];
     const T *arow = dzin + (size_t)r16 * ldw + q * P::EPV;
-    for (int kt = 0; kt < Kp / 16; ++kt) {
-      const int col = kt * 16 + r16;
-      float h[4];
-      get4T<BF16>(hp + (size_t)col * BP + row0 + 4 * q, h);
-      const f32x4 acc = tile_mma<BF16>(arow, Wt + (size_t)col * NK + q * P::EPV, nk);
-      float g[4];
+    for (int kt = 2 * wave; kt < Kp / 16; kt += 2 * (DEEP_THREADS / 64)) {  // (Kp = Hp: an even number of tiles)
+      float h[2][4];
+      f32x4 acc[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) g[i] = P::round(acc[i]);
-      if (dropout) {
-        bool keep[4];
-        deep_keep4(D, A, l - 1, row0 / 4 + q, col, keep);
+      for (int j = 0; j < 2; ++j) get4T<BF16>(hp + (size_t)((kt + j) * 16 + r16) * BP + row0 + 4 * q, h[j]);
+      tile_mma2<BF16>(arow, Wt + (size_t)(kt * 16 + r16) * NK + q * P::EPV,
+                      Wt + (size_t)((kt + 1) * 16 + r16) * NK + q * P::EPV, nk, acc[0], acc[1]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g[i] = P::round(g[i] * (keep[i] ? D.drop_scale : 0.f));
+      for (int j = 0; j < 2; ++j) {
+        const int col = (kt + j) * 16 + r16;
+        float g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = P::round(acc[j][i]);
+        if (dropout) {
+          bool keep[4];
+          deep_keep4(D, A, l - 1, row0 / 4 + q, col, keep);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) g[i] = P::round(g[i] * (keep[i] ? D.drop_scale : 0.f));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          g[i] = h[j][i] > 0.f ? g[i] : 0.f;
+          dzout[(size_t)(4 * q + i) * ldw + col] = P::from_f32(g[i]);
+        }
+        put4T<BF16>(zp + (size_t)col * BP + row0 + 4 * q, g);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        g[i] = h[i] > 0.f ? g[i] : 0.f;
-        dzout[(size_t)(4 * q + i) * ldw + col] = P::from_f32(g[i]);
-      }
-      put4T<BF16>(zp + (size_t)col * BP + row0 + 4 * q, g);
     }
     __syncthreads();
     T *t_ = dzin;
@@ -415,7 +438,23 @@ __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  for (int ks = 0; ks < nk; ++ks) {
+  int ks = 0;
+  for (; ks + 2 <= nk; ks += 2) {  // two k-steps (10 fragments) requested before the first MFMA
+    uint4 a[2], b[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      a[u] = ldg16(Z + (size_t)(ks + u) * P::KM);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) b[u][t] = ldg16(X + (size_t)t * 16 * BP + (size_t)(ks + u) * P::KM);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bsum += frag_sum<BF16>(a[u]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) P::mma(a[u], b[u][t], acc[t]);
+    }
+  }
+  for (; ks < nk; ++ks) {
     const uint4 a = ldg16(Z + (size_t)ks * P::KM);
     uint4 b[4];
 #pragma unroll
@@ -683,14 +722,14 @@ hipError_t deep_step(DeepTrainer *t, const DeepStep &a, hipStream_t st, hipEvent
   if (ev && (e = hipEventRecord(ev[k], st)) != hipSuccess) return e;
   DEEP_EV(0);
   if (t->bf16)
-    hipLaunchKernelGGL(kd_forward<true>, gf, dim3(64), t->lds_bytes, st, t->dD, a);
+    hipLaunchKernelGGL(kd_forward<true>, gf, dim3(DEEP_THREADS), t->lds_bytes, st, t->dD, a);
   else
-    hipLaunchKernelGGL(kd_forward<false>, gf, dim3(64), t->lds_bytes, st, t->dD, a);
+    hipLaunchKernelGGL(kd_forward<false>, gf, dim3(DEEP_THREADS), t->lds_bytes, st, t->dD, a);
   DEEP_EV(1);
   if (t->bf16)
-    hipLaunchKernelGGL(kd_backward<true>, gb, dim3(64), t->lds_bytes, st, t->dD, a);
+    hipLaunchKernelGGL(kd_backward<true>, gb, dim3(DEEP_THREADS), t->lds_bytes, st, t->dD, a);
   else
-    hipLaunchKernelGGL(kd_backward<false>, gb, dim3(64), t->lds_bytes, st, t->dD, a);
+    hipLaunchKernelGGL(kd_backward<false>, gb, dim3(DEEP_THREADS), t->lds_bytes, st, t->dD, a);
   DEEP_EV(2);
   if (t->bf16)
     hipLaunchKernelGGL(kd_update<true>, gu, dim3(256), 0, st, t->dD, t->ditems, a);
@@ -708,9 +747,9 @@ hipError_t deep_infer(DeepTrainer *t, int which, const float *s, const float *a,
   const dim3 grid((unsigned)((n + 15) / 16));
   auto go = [&](int evn, int out_ld, int col0) {
     if (t->bf16)
-      hipLaunchKernelGGL(kd_infer<true>, grid, dim3(64), t->lds_bytes, st, t->dD, evn, s, a, n, out, out_ld, col0);
+      hipLaunchKernelGGL(kd_infer<true>, grid, dim3(DEEP_THREADS), t->lds_bytes, st, t->dD, evn, s, a, n, out, out_ld, col0);
     else
-      hipLaunchKernelGGL(kd_infer<false>, grid, dim3(64), t->lds_bytes, st, t->dD, evn, s, a, n, out, out_ld, col0);
+      hipLaunchKernelGGL(kd_infer<false>, grid, dim3(DEEP_THREADS), t->lds_bytes, st, t->dD, evn, s, a, n, out, out_ld, col0);
   };
   if (which == 0 || which == 3)
     for (int e = 0; e < D.E; ++e) go((which == 3 ? D.E + 2 : 0) + e, D.E, e);

@@ -286,6 +286,64 @@ __global__ __launch_bounds__(256, 2) void k_mlp_f32(const MlpArgs M, const float
   }
 }
 
+// Widths beyond 256 (up to 1024; ref:417-449 accepts any hidden_dim): one wave per 16 rows, the
+// activations ping-pong between two LDS images [16][lda], every B fragment one contiguous read of the
+// fragment-major image.  No register tiling across rows or n-tiles: this variant exists for coverage.
+__global__ __launch_bounds__(64) void k_mlp_wide(const MlpArgs M, const float *__restrict__ x, int64_t n, int x_stride,
+                                                 float *__restrict__ out, int out_stride) {
+  using P = Prec<false>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x, r = lane & 15, q = lane >> 4, lda = M.lda;
+  float *in = reinterpret_cast<float *>(smem), *nxt = in + 16 * lda;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  {
+    const int K0 = M.dims[0], K0p = round_up(K0, 16);
+    for (int e = lane; e < 16 * K0p; e += 64) {
+      const int rr = e / K0p, c = e - rr * K0p;
+      float v = 0.f;
+      if (row0 + rr < n && c < K0) v = ldg(x + (size_t)(row0 + rr) * x_stride + c);
+      in[rr * lda + c] = v;
+    }
+  }
+  __syncthreads();
+  for (int l = 0; l < M.n_layers; ++l) {
+    const int K = M.dims[l], N = M.dims[l + 1];
+    const int nk = round_up(K, 16) / 16, ntile = round_up(N, 16) / 16;
+    const float *Wf = M.Wf[l], *bias = M.b[l];
+    const bool last = l == M.n_layers - 1;
+    for (int nt = 0; nt < ntile; ++nt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < nk; ++ks) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(in + r * lda + ks * 16 + q * 4);
+        const uint4 b = ldg16(Wf + frag_off<P>(nt, ks, nk, lane));
+        P::mma(a, b, acc);
+      }
+      const int col = nt * 16 + r;
+      const float bv = col < N ? ldg(bias + col) : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t R = row0 + 4 * q + i;
+        float v = acc[i] + bv;
+        if (!last) {
+          v = col < N ? act_apply<2>(v, M.hidden_act) : 0.f;
+          if (M.drop_thr) {  // oracle/philox.py mlp_dropout_keep: block (row, unit / 4 | layer << 16), word unit % 4
+            const Philox4 ph = philox4x32_10((uint32_t)R, M.drop_call, (uint32_t)(col >> 2) | ((uint32_t)l << 16),
+                                             STREAM_MLP_DROPOUT, (uint32_t)M.drop_seed, (uint32_t)(M.drop_seed >> 32));
+            const uint32_t w = (col & 3) == 0 ? ph.x : (col & 3) == 1 ? ph.y : (col & 3) == 2 ? ph.z : ph.w;
+            v = w >= M.drop_thr ? v * M.drop_scale : 0.f;
+          }
+          nxt[(4 * q + i) * lda + col] = v;
+        } else if (col < N && R < n) {
+          stg(out + (size_t)R * out_stride + col, out_apply<2>(v, M.out_act));
+        }
+      }
+    }
+    __syncthreads();
+    float *t_ = in;
+    in = nxt, nxt = t_;
+  }
+}
+
 hipError_t launch_mlp_f32(const iqlhip_mlp_desc &d, const float *x, int64_t n, int x_stride, float *out,
                           int out_stride, hipStream_t st) {
   MlpArgs M;
@@ -322,6 +380,22 @@ hipError_t launch_mlp_f32(const iqlhip_mlp_desc &d, const float *x, int64_t n, i
   size_t sm = (size_t)MROWS * M.lda * sizeof(float);
   const int nt_last = round_up(d.dims[d.n_layers], 16) / 16;
   if (nt_last < 4 && sm < (size_t)4 * nt_last * 4 * 64 * 16) sm = (size_t)4 * nt_last * 4 * 64 * 16;
+  bool wide = false;
+  for (int i = 0; i <= d.n_layers; ++i) wide |= d.dims[i] > 256;
+  if (wide) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_wide), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+    if (e == hipSuccess) {
+      int maxw = maxd;
+      if (d.dims[d.n_layers] > maxw) maxw = d.dims[d.n_layers];
+      M.lda = round_up(maxw, 16) + 4;
+      hipLaunchKernelGGL(k_mlp_wide, dim3((unsigned)((n + 15) / 16)), dim3(64), (size_t)2 * 16 * M.lda * sizeof(float),
+                         st, M, x, n, x_stride, out, out_stride);
+      e = hipGetLastError();
+    }
+    (void)hipFreeAsync(wf, st);
+    return e;
+  }
   // (set on every call: the attribute is per device, and a process may drive several)
   const int act = (d.hidden_act >= 8 || d.out_act >= 8) ? 2 : d.hidden_act;  // instantiation, see act_apply
   auto kern = act == 0 ? k_mlp_f32<0> : act == 1 ? k_mlp_f32<1> : k_mlp_f32<2>;

@@ -59,8 +59,14 @@ def sample_indices(seed, step, batch, n_rows):
     return (r0.astype(np.uint64) % np.uint64(n_rows)).astype(np.int64)
 
 
+def dropout_stream(l):
+    """Philox stream of the Dropout behind hidden layer ``l`` (0-based): 1 and 2 for the two hidden layers of
+    the default networks, 8 + l for deeper ones (csrc/iql_deep.hip drop_stream; 3 is taken, see below)."""
+    return STREAM_DROPOUT1 + l if l < 2 else 8 + l
+
+
 def dropout_keep(seed, step, layer, batch, hidden, p):
-    """Keep mask [batch, hidden] of dropout layer ``layer`` (1 or 2) at ``step``.
+    """Keep mask [batch, hidden] of the dropout layer with stream id ``layer`` (dropout_stream) at ``step``.
 
     One Philox call covers 4 consecutive batch rows of one hidden unit (the four
     accumulator registers a lane holds in the MFMA C/D layout): counter word 0 =

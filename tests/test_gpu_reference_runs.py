@@ -183,24 +183,26 @@ def test_mlp_forward_with_active_dropout_matches_the_philox_oracle():
     """MLP.forward in train mode (ref:436-437; GaussianPolicy.act in train mode, ref:476-482):
     masks from oracle/philox.py:mlp_dropout_keep, kept values times float(1 / (1 - p))."""
     import iqlpref_amd as ia
-    S, A, H, n, p = 11, 3, 64, 133, 0.25
-    torch.manual_seed(77)
-    actor = ia.GaussianPolicy(S, A, 1.0, hidden_dim=H, dropout=p).to(DEV)
-    x = torch.randn(n, S, device=DEV)
-    lin = [(l.weight.detach().cpu().numpy().astype(np.float64), l.bias.detach().cpu().numpy().astype(np.float64))
-           for l in actor.net.linears()]
+    S, A, n, p = 11, 3, 133, 0.25
     scale = np.float32(1.0) / np.float32(1.0 - p)
-    outs = []
-    for call in range(2):
-        got = actor(x).mean.cpu().numpy()  # train mode: dropout active
-        h = x.cpu().numpy().astype(np.float64)
-        for li, (W, b) in enumerate(lin[:2]):
-            keep = philox.mlp_dropout_keep(77, call, li, n, H, p)
-            h = np.maximum(h @ W.T + b, 0.0) * keep * np.float64(scale)
-        want = np.tanh(h @ lin[2][0].T + lin[2][1])
-        np.testing.assert_allclose(got, want, atol=3e-6, rtol=0)
-        outs.append(got)
-    assert not np.array_equal(outs[0], outs[1])  # a fresh mask per call
+    # (the default shape; three hidden layers of a width only the wide variant of the kernel takes)
+    for H, NH in ((64, 2), (320, 3)):
+        torch.manual_seed(77)
+        actor = ia.GaussianPolicy(S, A, 1.0, hidden_dim=H, n_hidden=NH, dropout=p).to(DEV)
+        x = torch.randn(n, S, device=DEV)
+        lin = [(l.weight.detach().cpu().numpy().astype(np.float64), l.bias.detach().cpu().numpy().astype(np.float64))
+               for l in actor.net.linears()]
+        outs = []
+        for call in range(2):
+            got = actor(x).mean.cpu().numpy()  # train mode: dropout active
+            h = x.cpu().numpy().astype(np.float64)
+            for li, (W, b) in enumerate(lin[:-1]):
+                keep = philox.mlp_dropout_keep(77, call, li, n, H, p)
+                h = np.maximum(h @ W.T + b, 0.0) * keep * np.float64(scale)
+            want = np.tanh(h @ lin[-1][0].T + lin[-1][1])
+            np.testing.assert_allclose(got, want, atol=3e-6, rtol=0)
+            outs.append(got)
+        assert not np.array_equal(outs[0], outs[1])  # a fresh mask per call
     keep = philox.mlp_dropout_keep(77, 0, 0, 4096, 256, p)
     assert abs(keep.mean() - (1 - p)) < 5e-3
     actor.eval()

@@ -42,7 +42,10 @@ def test_mlp_forward_kernel_shapes():
     import iqlpref_amd as ia
     rng = np.random.default_rng(0)
     for dims, w_in_out, act in (([37, 256, 256, 1], True, "relu"), ([6, 8, 8, 1], True, "relu"),
-                                ([45, 256, 256, 24], False, "relu"), ([13, 100, 7], True, "tanh")):
+                                ([45, 256, 256, 24], False, "relu"), ([13, 100, 7], True, "tanh"),
+                                # widths beyond 256: the one-wave-per-16-rows variant (k_mlp_wide)
+                                ([37, 384, 384, 1], False, "relu"), ([29, 1000, 8], True, "tanh"),
+                                ([300, 17, 1024, 33, 5], False, "relu")):
         ws = [rng.standard_normal((dims[i], dims[i + 1])).astype(np.float32) / np.sqrt(dims[i])
               for i in range(len(dims) - 1)]
         bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) * 0.1 for i in range(len(dims) - 1)]

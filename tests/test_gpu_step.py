@@ -394,6 +394,27 @@ def test_shapes_beyond_the_goldens_vs_oracle(gh, S, A, H, B, det, drop, E, mode)
     if mode == "fp32" and (S, A, H, B, det, drop, E) in ((17, 6, 256, 1024, True, None, 3), (29, 8, 256, 256, False, None, 8),
                                                          (45, 24, 256, 1024, False, 0.1, 2)):
         pytest.skip("round-4 cases: they exist for the throughput kernels, which are bf16 only")
+    _shape_case(gh, S, A, H, 2, B, det, drop, E, mode)
+
+
+@pytest.mark.parametrize("S,A,H,NH,B,det,drop,E", [
+    (29, 8, 384, 2, 256, False, None, 2),    # the default depth, a width beyond the tuned step's
+    (17, 6, 512, 3, 64, True, None, 2),      # wide and deep
+    (11, 3, 1000, 1, 32, False, None, 2),    # one hidden layer, near the widest (LDS rows beyond 64 KB in fp32)
+    (45, 24, 100, 3, 48, False, 0.1, 2),     # Philox dropout masks behind three hidden layers (streams 1, 2, 10)
+    (29, 8, 80, 5, 1024, False, None, 4),    # E = 4 critics, batch 1024
+    (17, 6, 24, 6, 16, True, 0.2, 3),        # the deepest, one 16-row slab
+    (29, 8, 256, 2, 64, False, None, 2)])    # (IQLHIP_FORCE_GENERAL only: the default shape through the general step)
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_general_step_shapes_vs_oracle(gh, S, A, H, NH, B, det, drop, E, mode):
+    """Depths and widths only the general layer-wise step runs (ref:417-449: any n_hidden / hidden_dim): HIP vs the
+    oracle, which tests/test_oracle_golden.py pins to reference runs at n_hidden = 1, 3, 4 (TRAJ_SHAPES)."""
+    if NH == 2 and H == 256 and not os.environ.get("IQLHIP_FORCE_GENERAL"):
+        pytest.skip("the tuned step takes this shape")
+    _shape_case(gh, S, A, H, NH, B, det, drop, E, mode, after_a_kink=0.5)
+
+
+def _shape_case(gh, S, A, H, NH, B, det, drop, E, mode, after_a_kink=None):
     import iqlpref_amd as ia
     rng = np.random.default_rng(B)
     N = 2000
@@ -403,25 +424,29 @@ def test_shapes_beyond_the_goldens_vs_oracle(gh, S, A, H, B, det, drop, E, mode)
             "next_observations": rng.standard_normal((N, S)).astype(np.float32),
             "terminals": (rng.uniform(size=N) < 0.05).astype(np.float32)}
     torch.manual_seed(B)
-    q = ia.TwinQ(S, A, hidden_dim=H) if E == 2 else ia.EnsembleQ(S, A, hidden_dim=H, n_critics=E)
-    v = ia.ValueFunction(S, hidden_dim=H)
-    actor = (ia.DeterministicPolicy if det else ia.GaussianPolicy)(S, A, 1.0, hidden_dim=H, dropout=drop)
+    q = ia.TwinQ(S, A, hidden_dim=H, n_hidden=NH) if E == 2 else \
+        ia.EnsembleQ(S, A, hidden_dim=H, n_hidden=NH, n_critics=E)
+    v = ia.ValueFunction(S, hidden_dim=H, n_hidden=NH)
+    actor = (ia.DeterministicPolicy if det else ia.GaussianPolicy)(S, A, 1.0, hidden_dim=H, n_hidden=NH, dropout=drop)
     sd = lambda m: {k: t.detach().numpy().copy() for k, t in m.state_dict().items()}
-    hyper = dict(s_dim=S, a_dim=A, hidden=H, deterministic=det, dropout=drop, iql_tau=0.8, beta=3.0,
+    hyper = dict(s_dim=S, a_dim=A, hidden=H, n_hidden=NH, deterministic=det, dropout=drop, iql_tau=0.8, beta=3.0,
                  max_steps=1000, discount=0.99, tau=0.005, n_rows=N, n_critics=E)
     nets = (sd(q), sd(v), sd(actor))
     tr = gh.make_trainer(hyper, nets, mode, seed=7, keep_grads=True)
+    general = NH != 2 or H not in (64, 128, 256) or bool(os.environ.get("IQLHIP_FORCE_GENERAL"))
+    assert tr.step_kind(B) == ("general" if general else "tuned")
     assert len(tr.qf.critics()) == E and tr.forward("q", torch.zeros(2, S, device=gh.DEV),
                                                      torch.zeros(2, A, device=gh.DEV)).shape == (2, E)
     buf = gh.make_buffer(hyper, data)
     K = 3
     o = helpers.make_oracle(hyper, nets, mode)
+    kinked = set()
     got = np.zeros((K, 3))
     for t in range(K):
         got[t] = tr.train_steps(buf, 1, B, graph_unroll=0).cpu().numpy()[0]
         km = None
         if drop:
-            km = [philox.dropout_keep(7, t, 1, B, H, drop), philox.dropout_keep(7, t, 2, B, H, drop)]
+            km = [philox.dropout_keep(7, t, philox.dropout_stream(l), B, H, drop) for l in range(NH)]
         out = o.train(orc.gather_batch(data, philox.sample_indices(7, t, B, N)), km)
         np.testing.assert_allclose(got[t], [out["value_loss"], out["q_loss"], out["actor_loss"]],
                                    rtol=3e-5 if mode == "fp32" else 6e-3)
@@ -437,6 +462,18 @@ def test_shapes_beyond_the_goldens_vs_oracle(gh, S, A, H, B, det, drop, E, mode)
         for which, mod in (("q", tr.qf), ("v", tr.vf), ("actor", tr.actor)):
             tight = mode == "fp32" and o.last_margin[which] > 1e-5
             bound = 5e-5 if tight else max(4.0 / B, 2e-2 if mode == "bf16" else 0.0)
+            if after_a_kink is not None:
+                # The deeper / wider nets of the general step meet a kink in most runs (512 x 3 x 64 pre-activations
+                # per evaluation).  A relu'(z) that falls the other way moves its unit's row by the WHOLE weight
+                # of that sample's delta (measured 8.7 % of the largest entry at batch 64), and from then on this
+                # network's parameters differ from the oracle's by sign-like Adam steps, i.e. the two runs are
+                # different trajectories of ONE net (tools/deep_probe.py: the other nets stay bit-identical to the
+                # oracle in bf16, 3e-7 in fp32).  So: a net that met a kink is only bounded loosely from that
+                # step on; every other net keeps its bound.
+                if o.last_margin[which] < 1e-5:
+                    kinked.add(which)
+                if which in kinked:
+                    bound = after_a_kink
             for name, p in mod.named_parameters():
                 want = o.last_grads[which][name]
                 err = float(np.abs(p.grad.cpu().numpy() - want).max() / (np.abs(want).max() + 1e-30))
@@ -447,9 +484,13 @@ def test_shapes_beyond_the_goldens_vs_oracle(gh, S, A, H, B, det, drop, E, mode)
         for k, t in mod.state_dict().items():
             # With the gradients pinned above, the parameters only need the sign-like-step bound:
             # no element may move further from the oracle than the steps themselves (K * lr).
+            # (a net that met a kink -- general-step cases, above -- and the oracle's copy of it are two
+            # trajectories: they may step in opposite directions, 2 lr apart per step)
+            hit = {"qf": "q", "q_target": "q"}.get(name, name) in kinked
             diff = np.abs(t.cpu().numpy() - opar[k])
-            assert diff.max() < K * 3e-4 * 1.01 + 2e-6, f"{name}/{k}: max {diff.max():.3e}"
-            if mode == "fp32":  # and all but a vanishing fraction agree to fp32 rounding (a small tensor may
+            assert diff.max() < (2 if hit else 1) * K * 3e-4 * 1.01 + 2e-6, f"{name}/{k}: max {diff.max():.3e}"
+            if mode == "fp32" and not hit:
+                # and all but a vanishing fraction agree to fp32 rounding (a small tensor may
                 # hold a few such entries: 1 of the 4,352 of a 256 x 17 first layer is 2.3e-4 of it)
                 assert (diff > 2e-6).sum() <= max(3, 1e-4 * diff.size), f"{name}/{k}: {(diff > 2e-6).mean():.2e} of elements off"
 
@@ -486,6 +527,66 @@ def test_seed_group_matches_separate_runs(gh, mode):
     group.close()
     solo = group.trainers[1].train_steps(buf, 5, B, graph_unroll=2).cpu().numpy()
     np.testing.assert_array_equal(solo, alone[1].train_steps(buf, 5, B, graph_unroll=2).cpu().numpy())
+
+
+def test_general_step_seeds_checkpoint_and_forward(gh, tmp_path):
+    """Trainers of a shape only the general step runs (three hidden layers of 96 units, the reference's own
+    initial weights: traj_deep3_w96): a SeedGroup steps them one by one on their own streams (group launches
+    exist for the tuned step only) = the same seeds run alone, bit for bit; a checkpoint written mid-run and
+    loaded into a fresh trainer continues the run bit for bit (ref:664-688, keys of a four-Linear MLP);
+    iqlhip_forward on the live weights = the oracle's forward."""
+    import iqlpref_amd as ia
+    d, hyper, data, nets = helpers.load_traj("traj_deep3_w96", "bf16")
+    B = hyper["batch"]
+    buf = gh.make_buffer(hyper, data)
+    seeds = (3, 4, 5)
+    alone = [gh.make_trainer(hyper, nets, "bf16", seed=s) for s in seeds]
+    assert alone[0].step_kind(B) == "general"
+    want = [t.train_steps(buf, 25, B).cpu().numpy() for t in alone]
+    members = [gh.make_trainer(hyper, nets, "bf16", seed=s) for s in seeds]
+    with pytest.raises(ValueError, match="tuned step"):
+        ia.SeedGroup(members, mode="group")
+    group = ia.SeedGroup(members, chunk=10)
+    assert group.mode == "streams"
+    got = group.train_steps(buf, 25, B, return_losses=True)
+    group.synchronize()
+    for w, g, ta, tg in zip(want, got, alone, group.trainers):
+        np.testing.assert_array_equal(w, g.cpu().numpy())
+        assert torch.equal(ta._params, tg._params) and torch.equal(ta._target, tg._target)
+        assert torch.equal(ta._exp_avg, tg._exp_avg) and torch.equal(ta._exp_avg_sq, tg._exp_avg_sq)
+    assert not np.array_equal(want[0], want[1])
+    # checkpoint mid-run -> fresh trainer -> the same continuation
+    sd = alone[0].state_dict()
+    assert list(sd["vf"].keys()) == [f"v.net.{i}.{w}" for i in (0, 2, 4, 6) for w in ("weight", "bias")]
+    path = str(tmp_path / "deep.pt")
+    torch.save(sd, path)
+    fresh = gh.make_trainer(hyper, nets, "bf16", seed=3)
+    fresh.load_state_dict(torch.load(path, weights_only=True))
+    assert fresh.total_it == 25
+    # (the reference's checkpoint holds no target network, ref:664-674: the continuation is bit-identical
+    # once the target is carried over, as tests/test_gpu_long_horizon.py does for the reference's own resume)
+    with torch.no_grad():
+        fresh._target.copy_(alone[0]._target)
+    fresh.sync_weights()
+    a = alone[0].train_steps(buf, 10, B).cpu().numpy()
+    b = fresh.train_steps(buf, 10, B).cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+    assert torch.equal(alone[0]._params, fresh._params)
+    # forward passes on the live weights against the oracle on the same weights
+    tr = alone[1]
+    sdn = lambda m: {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(0)
+    s_np = rng.standard_normal((37, hyper["s_dim"])).astype(np.float32)
+    a_np = rng.uniform(-1, 1, (37, hyper["a_dim"])).astype(np.float32)
+    st, at = torch.from_numpy(s_np).to(gh.DEV), torch.from_numpy(a_np).to(gh.DEV)
+    qs, _ = orc.critics_all(sdn(tr.qf), s_np, a_np, "bf16")
+    np.testing.assert_allclose(tr.forward("q", st, at).cpu().numpy(), np.stack(qs, 1), rtol=2e-2, atol=2e-3)
+    qt, _ = orc.critics_all(sdn(tr.q_target), s_np, a_np, "bf16")
+    np.testing.assert_allclose(tr.forward("q_target", st, at).cpu().numpy(), np.stack(qt, 1), rtol=2e-2, atol=2e-3)
+    vv, _ = orc.value_forward(sdn(tr.vf), s_np, "bf16")
+    np.testing.assert_allclose(tr.forward("v", st).cpu().numpy().reshape(-1), vv, rtol=2e-2, atol=2e-3)
+    mean, _, _ = orc.policy_forward(sdn(tr.actor), s_np, "bf16")
+    np.testing.assert_allclose(tr.forward("actor", st).cpu().numpy(), mean, rtol=2e-2, atol=4e-3)
 
 
 @pytest.mark.parametrize("mode,n_seeds", [("group", 8), ("group", 2), ("split", 8)])
