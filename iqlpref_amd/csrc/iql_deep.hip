@@ -382,17 +382,28 @@ __global__ __launch_bounds__(DEEP_THREADS) void kd_backward(const DeepDesc *__re
 }
 
 // ------------------------------------------------------------------------
-// kd_update: one work-group (4 waves) per 64 x 64 tile of a weight matrix; wave w owns out-features
-// [o0 + 16 w, +16) x the tile's four 16-wide in-feature groups.
+// kd_update: one work-group (4 waves) per 64 x 64 tile of a weight matrix.
 // ------------------------------------------------------------------------
+// sum of n floats `stride` apart, added in index order; eight loads are in flight at a time (a rolled
+// load-add loop is one memory round trip per element: 16 slabs were 11 us of the update launch)
+__device__ __forceinline__ float ordered_sum(const float *p, int stride, int n) {
+  float s = 0.f;
+  for (int k0 = 0; k0 < n; k0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ldg(p + (size_t)(k0 + u < n ? k0 + u : n - 1) * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += k0 + u < n ? v[u] : 0.f;
+  }
+  return s;
+}
+
 template <bool BF16>
 __device__ __forceinline__ void deep_misc(const DeepDesc &D, const DeepStep &A) {
   __shared__ float lm[MAX_TRAIN];
   const int tid = threadIdx.x, nslab = D.nslab;
   if (tid < D.ntrain) {
-    float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += ldg(D.lossp + (size_t)tid * nslab + k);
-    lm[tid] = s / (float)D.B;
+    lm[tid] = ordered_sum(D.lossp + (size_t)tid * nslab, 1, nslab) / (float)D.B;
   }
   __syncthreads();
   if (tid == 0 && A.losses_out) {
@@ -403,8 +414,7 @@ __device__ __forceinline__ void deep_misc(const DeepDesc &D, const DeepStep &A) 
     stg(A.losses_out + 2, lm[D.net_a]);
   }
   if (!D.deterministic && tid < D.A) {  // log_std (ref:452-474): std = exp(clamp(log_std))
-    float gs = 0.f;
-    for (int k = 0; k < nslab; ++k) gs += ldg(D.lsp + (size_t)k * D.A + tid);
+    const float gs = ordered_sum(D.lsp + tid, D.A, nslab);
     const int64_t o = D.off_log_std + tid;
     float p = ldg(D.params + o), m = ldg(D.exp_avg + o), v = ldg(D.exp_avg_sq + o);
     const bool inside = p >= -20.f && p <= 2.f;
@@ -428,80 +438,138 @@ __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp
     deep_misc<BF16>(D, A);
     return;
   }
+  // Two orientations of the same tile.  Rows of the [out][in] tensors that start on 16-byte boundaries
+  // (in-features a multiple of 4: every hidden layer of such a width) are computed TRANSPOSED,
+  // dW^T = X^T dZ: in the MFMA C layout a lane then holds 4 consecutive in-features k of ONE out-feature n,
+  // i.e. 16 contiguous bytes -- masters, moments, target and compute copies move as 16-byte (8-byte bf16)
+  // accesses.  Other shapes (the first layer: in-features = state_dim [+ action_dim]) keep dW = dZ^T X, where
+  // the 16 lanes of a row group hold 16 consecutive k of one n: 64-byte runs of scalar accesses (the
+  // transposed form there is 64 scattered words per instruction: the first layer's tiles took 6 of the
+  // launch's 12.8 us).  The wave's 16 rows come from operand P, the four 16-wide column groups from Q.
   const DeepNet &N = D.net[it.net];
   const int l = it.layer, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q = lane >> 4;
   const int BP = D.BP, nk = BP / P::KM;
-  const int ob = it.o0 + 16 * wave, Nn = N.N[l], Kn = N.K[l], Kpad = N.Kpad[l], NKp = N.NKpad[l];
-  const T *Z = reinterpret_cast<const T *>(N.dzT[l]) + (size_t)(ob + r16) * BP + q * P::EPV;
-  const T *X = reinterpret_cast<const T *>(N.hT[l]) + (size_t)(it.i0 + r16) * BP + q * P::EPV;
+  const int Nn = N.N[l], Kn = N.K[l], Kpad = N.Kpad[l], NKp = N.NKpad[l];
+  const bool vec = (Kn & 3) == 0;  // (scalar)
+  const T *Xp = reinterpret_cast<const T *>(N.hT[l]) + (size_t)(it.i0 + r16) * BP + q * P::EPV;
+  const T *Zp = reinterpret_cast<const T *>(N.dzT[l]) + (size_t)(it.o0 + r16) * BP + q * P::EPV;
+  const T *Pop = (vec ? Xp : Zp) + (size_t)16 * wave * BP, *Qop = vec ? Zp : Xp;
+  // bias = sum of the deltas over the batch: from the dZ fragments, by the tiles of the first column block
+  const bool bias_q = vec && it.i0 == 0 && wave == 0, bias_p = !vec && it.i0 == 0;  // (scalar)
   f32x4 acc[4];
+  float bsum[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}, bsum[t] = 0.f;
   int ks = 0;
-  for (; ks + 2 <= nk; ks += 2) {  // two k-steps (10 fragments) requested before the first MFMA
-    uint4 a[2], b[2][4];
+  for (; ks + 4 <= nk; ks += 4) {  // four k-steps (20 fragments) requested before the first MFMA
+    uint4 a[4], b[4][4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      a[u] = ldg16(Z + (size_t)(ks + u) * P::KM);
+    for (int u = 0; u < 4; ++u) {
+      a[u] = ldg16(Pop + (size_t)(ks + u) * P::KM);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) b[u][t] = ldg16(X + (size_t)t * 16 * BP + (size_t)(ks + u) * P::KM);
+      for (int t = 0; t < 4; ++t) b[u][t] = ldg16(Qop + (size_t)t * 16 * BP + (size_t)(ks + u) * P::KM);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      bsum += frag_sum<BF16>(a[u]);
+    for (int u = 0; u < 4; ++u) {
+      if (bias_p) bsum[0] += frag_sum<BF16>(a[u]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) P::mma(a[u], b[u][t], acc[t]);
+      for (int t = 0; t < 4; ++t) {
+        if (bias_q) bsum[t] += frag_sum<BF16>(b[u][t]);
+        P::mma(a[u], b[u][t], acc[t]);
+      }
     }
   }
   for (; ks < nk; ++ks) {
-    const uint4 a = ldg16(Z + (size_t)ks * P::KM);
-    uint4 b[4];
+    const uint4 a = ldg16(Pop + (size_t)ks * P::KM);
+    if (bias_p) bsum[0] += frag_sum<BF16>(a);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) b[t] = ldg16(X + (size_t)t * 16 * BP + (size_t)ks * P::KM);
-    bsum += frag_sum<BF16>(a);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) P::mma(a, b[t], acc[t]);
+    for (int t = 0; t < 4; ++t) {
+      const uint4 b = ldg16(Qop + (size_t)t * 16 * BP + (size_t)ks * P::KM);
+      if (bias_q) bsum[t] += frag_sum<BF16>(b);
+      P::mma(a, b, acc[t]);
+    }
   }
   const float neg_step = A.coef.neg_step[N.group];
   T *wc = reinterpret_cast<T *>(N.wc[l]), *wt = reinterpret_cast<T *>(N.wt[l]), *tc = reinterpret_cast<T *>(N.tc[l]);
   const int64_t off_w = N.off_w[l], toff_w = N.toff_w[l];
+  if (vec) {
+    const int k0 = it.i0 + 16 * wave + 4 * q;  // (k0 + 3 < Kn whenever k0 < Kn: both are multiples of 4)
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int k = it.i0 + 16 * t + r16;
+    for (int t = 0; t < 4; ++t) {
+      const int n = it.o0 + 16 * t + r16;
+      if (n >= Nn || k0 >= Kn) continue;
+      const int64_t o = off_w + (int64_t)n * Kn + k0, to = toff_w + (int64_t)n * Kn + k0;
+      const float4 pp = __builtin_bit_cast(float4, ldg16(D.params + o)), mm = __builtin_bit_cast(float4, ldg16(D.exp_avg + o));
+      const float4 vv = __builtin_bit_cast(float4, ldg16(D.exp_avg_sq + o));
+      float p[4] = {pp.x, pp.y, pp.z, pp.w}, m[4] = {mm.x, mm.y, mm.z, mm.w}, v[4] = {vv.x, vv.y, vv.z, vv.w};
+      float tg[4] = {0.f, 0.f, 0.f, 0.f}, g[4];
+      if (N.has_target) {
+        const float4 tt = __builtin_bit_cast(float4, ldg16(D.target + to));
+        tg[0] = tt.x, tg[1] = tt.y, tg[2] = tt.z, tg[3] = tt.w;
+      }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = ob + 4 * q + i;
-      if (n < Nn && k < Kn) {
-        const float g = P::round(acc[t][i]);  // parameter gradients are the bf16 results widened (autocast)
-        const int64_t o = off_w + (int64_t)n * Kn + k;
-        float p = ldg(D.params + o), m = ldg(D.exp_avg + o), v = ldg(D.exp_avg_sq + o);
-        if (D.grads) stg(D.grads + o, g);
-        adam_apply<AF>(p, m, v, g, A.coef, neg_step);
-        stg(D.params + o, p), stg(D.exp_avg + o, m), stg(D.exp_avg_sq + o, v);
-        stg(wc + (size_t)n * Kpad + k, P::from_f32(p));
-        if (wt) stg(wt + (size_t)k * NKp + n, P::from_f32(p));
-        if (N.has_target) {
-          const int64_t to = toff_w + (int64_t)n * Kn + k;
-          const float tn = polyak(D, ldg(D.target + to), p);
-          stg(D.target + to, tn);
-          stg(tc + (size_t)n * Kpad + k, P::from_f32(tn));
+      for (int i = 0; i < 4; ++i) {
+        g[i] = P::round(acc[t][i]);  // parameter gradients are the bf16 results widened (autocast)
+        adam_apply<AF>(p[i], m[i], v[i], g[i], A.coef, neg_step);
+        if (N.has_target) tg[i] = polyak(D, tg[i], p[i]);
+      }
+      if (D.grads) stg16(D.grads + o, make_float4(g[0], g[1], g[2], g[3]));
+      stg16(D.params + o, make_float4(p[0], p[1], p[2], p[3]));
+      stg16(D.exp_avg + o, make_float4(m[0], m[1], m[2], m[3]));
+      stg16(D.exp_avg_sq + o, make_float4(v[0], v[1], v[2], v[3]));
+      put4T<BF16>(wc + (size_t)n * Kpad + k0, p);
+      if (N.has_target) {
+        stg16(D.target + to, make_float4(tg[0], tg[1], tg[2], tg[3]));
+        put4T<BF16>(tc + (size_t)n * Kpad + k0, tg);
+      }
+      if (wt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stg(wt + (size_t)(k0 + i) * NKp + n, P::from_f32(p[i]));
+      }
+    }
+  } else {
+    const int n0 = it.o0 + 16 * wave + 4 * q;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = it.i0 + 16 * t + r16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = n0 + i;
+        if (n < Nn && k < Kn) {
+          const float g = P::round(acc[t][i]);
+          const int64_t o = off_w + (int64_t)n * Kn + k;
+          float p = ldg(D.params + o), m = ldg(D.exp_avg + o), v = ldg(D.exp_avg_sq + o);
+          if (D.grads) stg(D.grads + o, g);
+          adam_apply<AF>(p, m, v, g, A.coef, neg_step);
+          stg(D.params + o, p), stg(D.exp_avg + o, m), stg(D.exp_avg_sq + o, v);
+          stg(wc + (size_t)n * Kpad + k, P::from_f32(p));
+          if (wt) stg(wt + (size_t)k * NKp + n, P::from_f32(p));
+          if (N.has_target) {
+            const int64_t to = toff_w + (int64_t)n * Kn + k;
+            const float tn = polyak(D, ldg(D.target + to), p);
+            stg(D.target + to, tn);
+            stg(tc + (size_t)n * Kpad + k, P::from_f32(tn));
+          }
         }
       }
     }
   }
-  if (it.i0 == 0) {  // bias: sum of the deltas over the batch (bf16(g.sum(0)) under autocast)
-    const float gs = P::round(xor32_sum(xor16_sum(bsum)));
-    const int n = ob + r16;
-    if (q == 0 && n < Nn) {
-      const int64_t o = N.off_b[l] + n;
-      float p = ldg(D.params + o), m = ldg(D.exp_avg + o), v = ldg(D.exp_avg_sq + o);
-      if (D.grads) stg(D.grads + o, gs);
-      adam_apply<AF>(p, m, v, gs, A.coef, neg_step);
-      stg(D.params + o, p), stg(D.exp_avg + o, m), stg(D.exp_avg_sq + o, v);
-      if (N.has_target) {
-        const int64_t to = N.toff_b[l] + n;
-        stg(D.target + to, polyak(D, ldg(D.target + to), p));
+  if (bias_q || bias_p) {  // bf16(g.sum(0)) under autocast
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (bias_p && t > 0) break;
+      const float gs = P::round(xor32_sum(xor16_sum(bsum[t])));
+      const int n = bias_q ? it.o0 + 16 * t + r16 : it.o0 + 16 * wave + r16;
+      if (q == 0 && n < Nn) {
+        const int64_t o = N.off_b[l] + n;
+        float p = ldg(D.params + o), m = ldg(D.exp_avg + o), v = ldg(D.exp_avg_sq + o);
+        if (D.grads) stg(D.grads + o, gs);
+        adam_apply<AF>(p, m, v, gs, A.coef, neg_step);
+        stg(D.params + o, p), stg(D.exp_avg + o, m), stg(D.exp_avg_sq + o, v);
+        if (N.has_target) {
+          const int64_t to = N.toff_b[l] + n;
+          stg(D.target + to, polyak(D, ldg(D.target + to), p));
+        }
       }
     }
   }
