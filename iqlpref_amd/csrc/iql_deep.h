@@ -13,7 +13,7 @@ constexpr int DEEP_MAX_H = 1024;
 
 // One Linear layer as an evaluation reads it.
 struct DeepLin {
-  const void *w;   // compute-precision copy [Npad][Kpad], zero padded
+  const void *w;   // compute-precision copy of W[N][K], zero padded to [Npad][Kpad], fragment-major (common.h fidx)
   const float *b;  // fp32 bias [N] (master or target arena)
   int32_t K, Kpad, N, Npad;
 };
@@ -31,8 +31,8 @@ struct DeepEval {
 struct DeepNet {
   int64_t off_w[DEEP_MAX_LIN], off_b[DEEP_MAX_LIN];    // parameter / moment / gradient arenas
   int64_t toff_w[DEEP_MAX_LIN], toff_b[DEEP_MAX_LIN];  // target arena (critics), else -1
-  void *wc[DEEP_MAX_LIN];  // compute copies [Npad][Kpad]
-  void *wt[DEEP_MAX_LIN];  // transposed copies [Kpad][NKpad] (layers >= 1: the backward GEMM's operand)
+  void *wc[DEEP_MAX_LIN];  // compute copies [Npad][Kpad], fragment-major
+  void *wt[DEEP_MAX_LIN];  // transposed copies [Kpad][NKpad], fragment-major (layers >= 1: the backward GEMM's operand)
   void *tc[DEEP_MAX_LIN];  // target compute copies (critics) or null
   void *hT[DEEP_MAX_LIN];  // hT[l]: input of layer l >= 1 = hidden activations after layer l - 1,
                            // feature-major [rows64(Kpad)][BP]; hT[0] = the batch's (s | a) plane

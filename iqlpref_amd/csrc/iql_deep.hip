@@ -95,7 +95,9 @@ __device__ __forceinline__ void deep_keep4(const DeepDesc &D, const DeepStep &A,
 }
 
 // Two 16 x 16 output tiles that share their A operand: acc_j = A[16][K] (LDS, row-major) x B_j[16][K]^T
-// (global, K-contiguous rows); K = nk MFMA steps.  Four steps of operands (8 global + 4 LDS fragments)
+// (global, fragment-major: brow_j = this lane's fragment of k-step 0, the next k-step one fragment on --
+// a wave-wide fragment load is one contiguous 1 KiB read; a row-major image made it 16 half-used lines
+// and the weight stream, not latency, bounds these kernels); K = nk MFMA steps.  Eight steps of operands (16 global + 8 LDS fragments)
 // are requested before the first MFMA of a chunk.
 template <bool BF16>
 __device__ __forceinline__ void tile_mma2(const typename Prec<BF16>::T *arow, const typename Prec<BF16>::T *brow0,
@@ -103,12 +105,27 @@ __device__ __forceinline__ void tile_mma2(const typename Prec<BF16>::T *arow, co
   using P = Prec<BF16>;
   acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
   int ks = 0;
+  for (; ks + 8 <= nk; ks += 8) {  // (a 256-wide layer in bf16 is ONE such chunk: one memory round trip per tile pair)
+    uint4 b0[8], b1[8], a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      b0[u] = ldg16(brow0 + (size_t)(ks + u) * 64 * P::EPV);
+      b1[u] = ldg16(brow1 + (size_t)(ks + u) * 64 * P::EPV);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const uint4 *>(arow + (size_t)(ks + u) * P::KM);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      P::mma(a[u], b0[u], acc0);
+      P::mma(a[u], b1[u], acc1);
+    }
+  }
   for (; ks + 4 <= nk; ks += 4) {
     uint4 b0[4], b1[4], a[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      b0[u] = ldg16(brow0 + (size_t)(ks + u) * P::KM);
-      b1[u] = ldg16(brow1 + (size_t)(ks + u) * P::KM);
+      b0[u] = ldg16(brow0 + (size_t)(ks + u) * 64 * P::EPV);
+      b1[u] = ldg16(brow1 + (size_t)(ks + u) * 64 * P::EPV);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const uint4 *>(arow + (size_t)(ks + u) * P::KM);
@@ -119,7 +136,7 @@ __device__ __forceinline__ void tile_mma2(const typename Prec<BF16>::T *arow, co
     }
   }
   for (; ks < nk; ++ks) {
-    const uint4 b0 = ldg16(brow0 + (size_t)ks * P::KM), b1 = ldg16(brow1 + (size_t)ks * P::KM);
+    const uint4 b0 = ldg16(brow0 + (size_t)ks * 64 * P::EPV), b1 = ldg16(brow1 + (size_t)ks * 64 * P::EPV);
     const uint4 a = *reinterpret_cast<const uint4 *>(arow + (size_t)ks * P::KM);
     P::mma(a, b0, acc0);
     P::mma(a, b1, acc1);
@@ -149,13 +166,16 @@ __device__ __forceinline__ void deep_layers(const DeepDesc &D, const DeepEval &N
       const bool two = nt + 1 < ntile;  // (the output layer may have a single tile: its twin is computed and dropped)
       const int col0 = nt * 16 + r16, col1 = two ? col0 + 16 : col0;
       f32x4 acc[2];
-      tile_mma2<BF16>(arow, W + (size_t)col0 * Kpad + q * P::EPV, W + (size_t)col1 * Kpad + q * P::EPV, nk, acc[0], acc[1]);
+      // (requested ahead of the weight fragments: a load behind the MFMAs is a memory round trip per tile pair)
+      const float braw[2] = {ldg(bias + (col0 < Nn ? col0 : 0)), ldg(bias + (col1 < Nn ? col1 : 0))};
+      tile_mma2<BF16>(arow, W + frag_off<P>(nt, 0, nk, lane), W + frag_off<P>(two ? nt + 1 : nt, 0, nk, lane), nk, acc[0],
+                      acc[1]);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (j == 1 && !two) break;
         const int col = j ? col1 : col0;
         // nn.Linear under autocast: bf16 inputs, weights AND bias, fp32 accumulation, bf16 result
-        const float bv = col < Nn ? P::round(ldg(bias + col)) : 0.f;
+        const float bv = col < Nn ? P::round(braw[j]) : 0.f;
         float z[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) z[i] = P::round(acc[j][i] + bv);
@@ -353,8 +373,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void kd_backward(const DeepDesc *__re
       f32x4 acc[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) get4T<BF16>(hp + (size_t)((kt + j) * 16 + r16) * BP + row0 + 4 * q, h[j]);
-      tile_mma2<BF16>(arow, Wt + (size_t)(kt * 16 + r16) * NK + q * P::EPV,
-                      Wt + (size_t)((kt + 1) * 16 + r16) * NK + q * P::EPV, nk, acc[0], acc[1]);
+      tile_mma2<BF16>(arow, Wt + frag_off<P>(kt, 0, nk, lane), Wt + frag_off<P>(kt + 1, 0, nk, lane), nk, acc[0], acc[1]);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int col = (kt + j) * 16 + r16;
@@ -449,7 +468,8 @@ __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp
   const DeepNet &N = D.net[it.net];
   const int l = it.layer, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q = lane >> 4;
   const int BP = D.BP, nk = BP / P::KM;
-  const int Nn = N.N[l], Kn = N.K[l], Kpad = N.Kpad[l], NKp = N.NKpad[l];
+  const int Nn = N.N[l], Kn = N.K[l];
+  const int nkw = N.Kpad[l] / P::KM, nkt = N.NKpad[l] / P::KM;  // k-steps per row of the copies W[n][k] / Wt[k][n]
   const bool vec = (Kn & 3) == 0;  // (scalar)
   const T *Xp = reinterpret_cast<const T *>(N.hT[l]) + (size_t)(it.i0 + r16) * BP + q * P::EPV;
   const T *Zp = reinterpret_cast<const T *>(N.dzT[l]) + (size_t)(it.o0 + r16) * BP + q * P::EPV;
@@ -517,14 +537,14 @@ __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp
       stg16(D.params + o, make_float4(p[0], p[1], p[2], p[3]));
       stg16(D.exp_avg + o, make_float4(m[0], m[1], m[2], m[3]));
       stg16(D.exp_avg_sq + o, make_float4(v[0], v[1], v[2], v[3]));
-      put4T<BF16>(wc + (size_t)n * Kpad + k0, p);
+      put4T<BF16>(wc + fidx<P>(n, k0, nkw), p);  // (4 consecutive, 4-aligned k of one row stay contiguous)
       if (N.has_target) {
         stg16(D.target + to, make_float4(tg[0], tg[1], tg[2], tg[3]));
-        put4T<BF16>(tc + (size_t)n * Kpad + k0, tg);
+        put4T<BF16>(tc + fidx<P>(n, k0, nkw), tg);
       }
       if (wt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stg(wt + (size_t)(k0 + i) * NKp + n, P::from_f32(p[i]));
+        for (int i = 0; i < 4; ++i) stg(wt + fidx<P>(k0 + i, n, nkt), P::from_f32(p[i]));
       }
     }
   } else {
@@ -542,13 +562,13 @@ __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp
           if (D.grads) stg(D.grads + o, g);
           adam_apply<AF>(p, m, v, g, A.coef, neg_step);
           stg(D.params + o, p), stg(D.exp_avg + o, m), stg(D.exp_avg_sq + o, v);
-          stg(wc + (size_t)n * Kpad + k, P::from_f32(p));
-          if (wt) stg(wt + (size_t)k * NKp + n, P::from_f32(p));
+          stg(wc + fidx<P>(n, k, nkw), P::from_f32(p));
+          if (wt) stg(wt + fidx<P>(k, n, nkt), P::from_f32(p));
           if (N.has_target) {
             const int64_t to = toff_w + (int64_t)n * Kn + k;
             const float tn = polyak(D, ldg(D.target + to), p);
             stg(D.target + to, tn);
-            stg(tc + (size_t)n * Kpad + k, P::from_f32(tn));
+            stg(tc + fidx<P>(n, k, nkw), P::from_f32(tn));
           }
         }
       }
@@ -583,14 +603,14 @@ __global__ __launch_bounds__(256) void kd_sync(const DeepDesc *__restrict__ Dp) 
   const DeepDesc &D = *Dp;
   const int net = blockIdx.y / D.NL, l = blockIdx.y % D.NL;
   const DeepNet &N = D.net[net];
-  const int Nn = N.N[l], Kn = N.K[l], Kpad = N.Kpad[l], NKp = N.NKpad[l];
+  const int Nn = N.N[l], Kn = N.K[l], nkw = N.Kpad[l] / P::KM, nkt = N.NKpad[l] / P::KM;
   T *wc = reinterpret_cast<T *>(N.wc[l]), *wt = reinterpret_cast<T *>(N.wt[l]), *tc = reinterpret_cast<T *>(N.tc[l]);
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)Nn * Kn; e += (int64_t)gridDim.x * 256) {
     const int n = (int)(e / Kn), k = (int)(e % Kn);
     const T pv = P::from_f32(ldg(D.params + N.off_w[l] + e));
-    stg(wc + (size_t)n * Kpad + k, pv);
-    if (wt) stg(wt + (size_t)k * NKp + n, pv);
-    if (N.has_target) stg(tc + (size_t)n * Kpad + k, P::from_f32(ldg(D.target + N.toff_w[l] + e)));
+    stg(wc + fidx<P>(n, k, nkw), pv);
+    if (wt) stg(wt + fidx<P>(k, n, nkt), pv);
+    if (N.has_target) stg(tc + fidx<P>(n, k, nkw), P::from_f32(ldg(D.target + N.toff_w[l] + e)));
   }
 }
 
