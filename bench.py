@@ -64,12 +64,14 @@ def synth_dataset(seed, n=N_ROWS):
     }
 
 
-def build_trainer(ia, torch, device, seed, precision, n_critics=2, dims=None, dropout=None, hyper=None):
+def build_trainer(ia, torch, device, seed, precision, n_critics=2, dims=None, dropout=None, hyper=None,
+                  hidden_dim=256, n_hidden=2):
     S, A = dims or (S_DIM, A_DIM)
     torch.manual_seed(seed)
-    q = (ia.TwinQ(S, A) if n_critics == 2 else ia.EnsembleQ(S, A, n_critics=n_critics)).to(device)
-    v = ia.ValueFunction(S).to(device)
-    actor = ia.GaussianPolicy(S, A, 1.0, dropout=dropout).to(device)
+    kw = dict(hidden_dim=hidden_dim, n_hidden=n_hidden)
+    q = (ia.TwinQ(S, A, **kw) if n_critics == 2 else ia.EnsembleQ(S, A, n_critics=n_critics, **kw)).to(device)
+    v = ia.ValueFunction(S, **kw).to(device)
+    actor = ia.GaussianPolicy(S, A, 1.0, dropout=dropout, **kw).to(device)
     vo = torch.optim.Adam(v.parameters(), lr=3e-4)
     qo = torch.optim.Adam(q.parameters(), lr=3e-4)
     ao = torch.optim.Adam(actor.parameters(), lr=3e-4)
@@ -536,6 +538,35 @@ def main():
                 del trp, bufp
             except Exception as e:
                 out["pen_config3"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_pen:
+            # a shape off the tuned step's (three hidden layers instead of two, ref:458-459 n_hidden): the general
+            # layer-wise step (csrc/iql_deep.hip), plain launches; its update kernel's share of the HBM roofline
+            # from HIP events only (no committed trace)
+            try:
+                import ctypes as C
+                trg = build_trainer(ia, torch, device, seed + 90, args.precision, n_hidden=3)
+                assert trg.step_kind(BATCH) == "general"
+                trg.train_steps(buf, 500, BATCH, return_losses=False)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                trg.train_steps(buf, 5_000, BATCH, return_losses=False)
+                torch.cuda.synchronize()
+                dtg = time.perf_counter() - t1
+                evg, _ = kernel_times(_lib, trg, buf, BATCH, 200)
+                byg, flg = C.c_double(), C.c_double()
+                cfgg = trg._cfg(BATCH)
+                _lib.check(_lib.load().iqlhip_step_cost(C.byref(cfgg), C.byref(byg), C.byref(flg)))
+                gath = 4.0 * BATCH * (2 * cfgg.state_dim + cfgg.action_dim + 2)
+                out["general_step"] = {
+                    "value": 5_000 / dtg, "unit": "steps/s", "us_per_step": dtg / 5_000 * 1e6, "n_hidden": 3,
+                    "hidden_dim": 256, "batch": BATCH, "bytes_per_step": byg.value,
+                    "kernel_us_events": {"kd_forward": evg[0], "kd_backward": evg[1], "kd_update": evg[2]},
+                    "kd_update_hbm_frac_events": (byg.value - gath) / (evg[2] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    "note": "the general layer-wise step on a shape the tuned three-kernel step does not take "
+                            "(coverage path: no rocprofv3 trace behind these figures); not `value`"}
+                del trg
+            except Exception as e:
+                out["general_step"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_relabel:
             try:
                 from tools import bench_relabel
