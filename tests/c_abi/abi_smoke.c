@@ -49,7 +49,7 @@ int main(void) {
   cfg.lr_q = cfg.lr_v = cfg.lr_actor = 3e-4;
   cfg.adam_beta1 = 0.9, cfg.adam_beta2 = 0.999, cfg.adam_eps = 1e-8;
   cfg.cosine_t_max = 1000, cfg.seed = 2024, cfg.n_critics = 0;
-  if (iqlhip_abi_version() != 5) return 2;
+  if (iqlhip_abi_version() != 6) return 2;
 
   int64_t off[IQLHIP_N_TENSORS], n_params = 0, n_target = 0;
   CHECK(iqlhip_arena_layout(&cfg, off, &n_params, &n_target));
