@@ -561,9 +561,12 @@ def main():
                     "value": 5_000 / dtg, "unit": "steps/s", "us_per_step": dtg / 5_000 * 1e6, "n_hidden": 3,
                     "hidden_dim": 256, "batch": BATCH, "bytes_per_step": byg.value,
                     "kernel_us_events": {"kd_forward": evg[0], "kd_backward": evg[1], "kd_update": evg[2]},
-                    "kd_update_hbm_frac_events": (byg.value - gath) / (evg[2] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    "roofline": roofline_block("kd_update (three hidden layers of 256 units)", byg.value - gath, evg[2],
+                                               "plain launches; HIP events around each kernel",
+                                               f"{PROFILE_TAG}_general_kernel_stats.csv", ("kd_update<true>",),
+                                               "plain launches under rocprofv3 --kernel-trace", _lib.build_tag()),
                     "note": "the general layer-wise step on a shape the tuned three-kernel step does not take "
-                            "(coverage path: no rocprofv3 trace behind these figures); not `value`"}
+                            "(coverage path); not `value`"}
                 del trg
             except Exception as e:
                 out["general_step"] = {"error": f"{type(e).__name__}: {e}"}

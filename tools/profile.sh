@@ -53,6 +53,11 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 find $OUT/pen -name "*kernel_stats.csv" -exec cp {} $OUT/pen_kernel_stats.csv \;
 rm -rf $OUT/ens $OUT/efetch $OUT/ewrite $OUT/pen
 echo "ens4 / pen done"
+# the general layer-wise step (three hidden layers of 256 units, batch 256): kernel trace + stats
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/gen -- python tools/general_run.py 256 3 256 2 3000 > $OUT/general.json
+find $OUT/gen -name "*kernel_stats.csv" -exec cp {} $OUT/general_kernel_stats.csv \;
+rm -rf $OUT/gen
+echo "general done"
 python tools/pmc_summary.py $OUT/gfetch 1 $OUT/group8_pmc_fetch_size.json > /dev/null
 python tools/pmc_summary.py $OUT/gwrite 1 $OUT/group8_pmc_write_size.json > /dev/null
 python tools/traffic_json.py $OUT/group8_pmc_fetch_size.json $OUT/group8_pmc_write_size.json $OUT/group8_traffic.json
