@@ -3,12 +3,12 @@
 // (ref:417-449 MLP, :452-543 the networks; ref:581-662 the step).  Same arithmetic (step_math.h),
 // same arenas, same index / dropout streams; three plain launches per step:
 //
-//   kd_forward   (2E+3 evaluations) x B/16 slabs, four waves each: the slab's 16 transitions gathered
+//   kd_forward   (2E+3 evaluations) x B/16 slabs, four or eight waves each: the slab's 16 transitions gathered
 //                from the packed replay rows, then every Linear on MFMA -- A fragments from a
 //                row-major LDS image of the previous layer's output, B fragments straight from the
 //                row-major compute copy W[n][k] in L2 -- with the hidden activations of the trained
 //                nets stored feature-major for the other two kernels.
-//   kd_backward  (E+2 trained nets) x B/16 slabs, four waves each: loss terms, d(out), then
+//   kd_backward  (E+2 trained nets) x B/16 slabs, four or eight waves each: loss terms, d(out), then
 //                dZ_{l-1} = (dZ_l W_l) * relu' layer by layer (B fragments from the transposed copies
 //                Wt[k][n]), deltas stored feature-major; per-slab loss partial sums.
 //   kd_update    64 x 64 tiles of every weight matrix: dW = dZ^T X (K = batch, both operands
@@ -143,7 +143,13 @@ __device__ __forceinline__ void tile_mma2(const typename Prec<BF16>::T *arow, co
   }
 }
 
-constexpr int DEEP_THREADS = 256;  // four waves share a slab's LDS images; wave w owns the tile pairs w, w + 4, ...
+// The waves of a slab share its LDS images; wave w owns the tile pairs w, w + W, ...  W = 4 or 8 (blockDim):
+// eight when a layer has that many pairs and the launch leaves CUs idle anyway (one seed at batch 256: 24.8k
+// against 20.8k steps/s at three hidden layers of 256 units, 18.1k against 14.6k at 512 units); four when
+// the launch fills the chip (E = 4 at batch 1024: 14.7k against 13.4k) or the layers are narrow (96 units:
+// 32.2k against 29.0k) -- deep_threads() below.
+// (two instantiations, THREADS = 256 / 512: one binary bounded for 512 threads costs the 256-thread launches
+// 10-20 %)
 
 // All Linear layers of one evaluation for the 16 rows whose inputs sit in `in` (LDS, row-major,
 // zero padded to the first layer's Kpad).  hidden(l, col, a[4]) receives the activations behind
@@ -162,7 +168,7 @@ __device__ __forceinline__ void deep_layers(const DeepDesc &D, const DeepEval &N
     const float *bias = Lk.b;
     const bool last = l == NL - 1;
     const T *arow = in + (size_t)r16 * ldw + q * P::EPV;
-    for (int nt = 2 * wave; nt < ntile; nt += 2 * (DEEP_THREADS / 64)) {
+    for (int nt = 2 * wave; nt < ntile; nt += 2 * ((int)blockDim.x >> 6)) {
       const bool two = nt + 1 < ntile;  // (the output layer may have a single tile: its twin is computed and dropped)
       const int col0 = nt * 16 + r16, col1 = two ? col0 + 16 : col0;
       f32x4 acc[2];
@@ -220,8 +226,8 @@ __device__ __forceinline__ int64_t deep_row_index(const DeepDesc &D, const DeepS
 // ------------------------------------------------------------------------
 // kd_forward: grid (B/16, 2E+3), four waves.
 // ------------------------------------------------------------------------
-template <bool BF16>
-__global__ __launch_bounds__(DEEP_THREADS) void kd_forward(const DeepDesc *__restrict__ Dp, const DeepStep A) {
+template <bool BF16, int THREADS>
+__global__ __launch_bounds__(THREADS) void kd_forward(const DeepDesc *__restrict__ Dp, const DeepStep A) {
   using P = Prec<BF16>;
   using T = typename P::T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -229,8 +235,8 @@ __global__ __launch_bounds__(DEEP_THREADS) void kd_forward(const DeepDesc *__res
   const DeepEval &N = D.ev[blockIdx.y];
   const int row0 = blockIdx.x * 16, q = (threadIdx.x & 63) >> 4, ldw = D.lds_w, BP = D.BP;
   T *bufA = reinterpret_cast<T *>(smem), *bufB = bufA + (size_t)16 * ldw;
-  // ---- the slab's inputs: 16 threads per row ----
-  {
+  // ---- the slab's inputs: 16 threads per row (the first 256 threads) ----
+  if (threadIdx.x < 256) {
     const int r = threadIdx.x >> 4, c0 = threadIdx.x & 15, row = row0 + r;
     const int64_t ix = deep_row_index(D, A, row);
     const float *src = A.rows + (size_t)ix * A.row_stride;
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void kd_forward(const DeepDesc *__res
 // Forward on dense inputs (iqlhip_forward): n rows of s [n][S] (and a [n][A]); out[row][col0 + j],
 // row stride out_ld.  Eval mode: no Dropout.
 template <bool BF16>
-__global__ __launch_bounds__(DEEP_THREADS) void kd_infer(const DeepDesc *__restrict__ Dp, int ev, const float *__restrict__ s,
+__global__ __launch_bounds__(256) void kd_infer(const DeepDesc *__restrict__ Dp, int ev, const float *__restrict__ s,
                                                const float *__restrict__ a, int64_t n, float *__restrict__ out,
                                                int out_ld, int col0) {
   using P = Prec<BF16>;
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void kd_infer(const DeepDesc *__restr
   const int q = (threadIdx.x & 63) >> 4, ldw = D.lds_w;
   const int64_t row0 = (int64_t)blockIdx.x * 16;
   T *bufA = reinterpret_cast<T *>(smem), *bufB = bufA + (size_t)16 * ldw;
-  {
+  if (threadIdx.x < 256) {
     const int r = threadIdx.x >> 4, c0 = threadIdx.x & 15;
     const int64_t row = row0 + r < n ? row0 + r : n - 1;
     const int K0 = N.lin[0].Kpad, in_dim = N.in_dim, S = D.S;
@@ -305,8 +311,8 @@ __global__ __launch_bounds__(DEEP_THREADS) void kd_infer(const DeepDesc *__restr
 // ------------------------------------------------------------------------
 // kd_backward: grid (B/16, E+2), four waves (the loss terms by the first, the layer walk by all).
 // ------------------------------------------------------------------------
-template <bool BF16>
-__global__ __launch_bounds__(DEEP_THREADS) void kd_backward(const DeepDesc *__restrict__ Dp, const DeepStep A) {
+template <bool BF16, int THREADS>
+__global__ __launch_bounds__(THREADS) void kd_backward(const DeepDesc *__restrict__ Dp, const DeepStep A) {
   using P = Prec<BF16>;
   using T = typename P::T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void kd_backward(const DeepDesc *__re
   const int ldw = D.lds_w, BP = D.BP, L = D.NL - 1;
   T *dzin = reinterpret_cast<T *>(smem), *dzout = dzin + (size_t)16 * ldw;
   // the output layer's delta tile is narrower than one MFMA K step: zero what the GEMM reads beyond it
-  for (int e = threadIdx.x; e < 16 * ldw; e += DEEP_THREADS) dzin[e] = P::from_f32(0.f);
+  for (int e = threadIdx.x; e < 16 * ldw; e += (int)blockDim.x) dzin[e] = P::from_f32(0.f);
   __syncthreads();
   // ---- loss terms and d(loss)/d(out) (ref:581-637) ----
   if (wave == 0) {
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void kd_backward(const DeepDesc *__re
     T *zp = reinterpret_cast<T *>(N.dzT[l - 1]);
     const int NK = N.NKpad[l], nk = NK / P::KM, Kp = N.Kpad[l];
     const T *arow = dzin + (size_t)r16 * ldw + q * P::EPV;
-    for (int kt = 2 * wave; kt < Kp / 16; kt += 2 * (DEEP_THREADS / 64)) {  // (Kp = Hp: an even number of tiles)
+    for (int kt = 2 * wave; kt < Kp / 16; kt += 2 * ((int)blockDim.x >> 6)) {  // (Kp = Hp: an even number of tiles)
       float h[2][4];
       f32x4 acc[2];
 #pragma unroll
@@ -772,8 +778,11 @@ hipError_t deep_create(DeepTrainer **out, const iqlhip_trainer_config &cfg, int 
     e = hipMemcpy(t->ditems, items.data(), items.size() * sizeof(DeepItem), hipMemcpyHostToDevice);
   if (e == hipSuccess && t->lds_bytes > 48 * 1024) {
     const int lb = (int)t->lds_bytes;
-    const void *fns[] = {(const void *)kd_forward<true>,  (const void *)kd_forward<false>, (const void *)kd_backward<true>,
-                         (const void *)kd_backward<false>, (const void *)kd_infer<true>,    (const void *)kd_infer<false>};
+    const void *fns[] = {(const void *)kd_forward<true, 256>,   (const void *)kd_forward<false, 256>,
+                         (const void *)kd_forward<true, 512>,   (const void *)kd_forward<false, 512>,
+                         (const void *)kd_backward<true, 256>,  (const void *)kd_backward<false, 256>,
+                         (const void *)kd_backward<true, 512>,  (const void *)kd_backward<false, 512>,
+                         (const void *)kd_infer<true>,          (const void *)kd_infer<false>};
     for (const void *f : fns)
       if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lb);
   }
@@ -802,22 +811,33 @@ hipError_t deep_sync_weights(DeepTrainer *t, hipStream_t st) {
 }
 
 // One step: three launches; ev (optional, 4 events) brackets them for the per-kernel timing.
+static int deep_threads(const DeepDesc &D, int n_wgs) { return D.Hp >= 256 && n_wgs <= 256 ? 512 : 256; }
+
 hipError_t deep_step(DeepTrainer *t, const DeepStep &a, hipStream_t st, hipEvent_t *ev) {
   const DeepDesc &D = t->D;
   const dim3 gf(D.nslab, D.nfwd), gb(D.nslab, D.ntrain), gu(t->n_items);
+  const int tf = deep_threads(D, D.nslab * D.nfwd), tb = deep_threads(D, D.nslab * D.ntrain);
   hipError_t e;
 #define DEEP_EV(k) \
   if (ev && (e = hipEventRecord(ev[k], st)) != hipSuccess) return e;
   DEEP_EV(0);
-  if (t->bf16)
-    hipLaunchKernelGGL(kd_forward<true>, gf, dim3(DEEP_THREADS), t->lds_bytes, st, t->dD, a);
+  if (t->bf16 && tf == 512)
+    hipLaunchKernelGGL((kd_forward<true, 512>), gf, dim3(512), t->lds_bytes, st, t->dD, a);
+  else if (t->bf16)
+    hipLaunchKernelGGL((kd_forward<true, 256>), gf, dim3(256), t->lds_bytes, st, t->dD, a);
+  else if (tf == 512)
+    hipLaunchKernelGGL((kd_forward<false, 512>), gf, dim3(512), t->lds_bytes, st, t->dD, a);
   else
-    hipLaunchKernelGGL(kd_forward<false>, gf, dim3(DEEP_THREADS), t->lds_bytes, st, t->dD, a);
+    hipLaunchKernelGGL((kd_forward<false, 256>), gf, dim3(256), t->lds_bytes, st, t->dD, a);
   DEEP_EV(1);
-  if (t->bf16)
-    hipLaunchKernelGGL(kd_backward<true>, gb, dim3(DEEP_THREADS), t->lds_bytes, st, t->dD, a);
+  if (t->bf16 && tb == 512)
+    hipLaunchKernelGGL((kd_backward<true, 512>), gb, dim3(512), t->lds_bytes, st, t->dD, a);
+  else if (t->bf16)
+    hipLaunchKernelGGL((kd_backward<true, 256>), gb, dim3(256), t->lds_bytes, st, t->dD, a);
+  else if (tb == 512)
+    hipLaunchKernelGGL((kd_backward<false, 512>), gb, dim3(512), t->lds_bytes, st, t->dD, a);
   else
-    hipLaunchKernelGGL(kd_backward<false>, gb, dim3(DEEP_THREADS), t->lds_bytes, st, t->dD, a);
+    hipLaunchKernelGGL((kd_backward<false, 256>), gb, dim3(256), t->lds_bytes, st, t->dD, a);
   DEEP_EV(2);
   if (t->bf16)
     hipLaunchKernelGGL(kd_update<true>, gu, dim3(256), 0, st, t->dD, t->ditems, a);
@@ -835,9 +855,9 @@ hipError_t deep_infer(DeepTrainer *t, int which, const float *s, const float *a,
   const dim3 grid((unsigned)((n + 15) / 16));
   auto go = [&](int evn, int out_ld, int col0) {
     if (t->bf16)
-      hipLaunchKernelGGL(kd_infer<true>, grid, dim3(DEEP_THREADS), t->lds_bytes, st, t->dD, evn, s, a, n, out, out_ld, col0);
+      hipLaunchKernelGGL(kd_infer<true>, grid, dim3(256), t->lds_bytes, st, t->dD, evn, s, a, n, out, out_ld, col0);
     else
-      hipLaunchKernelGGL(kd_infer<false>, grid, dim3(DEEP_THREADS), t->lds_bytes, st, t->dD, evn, s, a, n, out, out_ld, col0);
+      hipLaunchKernelGGL(kd_infer<false>, grid, dim3(256), t->lds_bytes, st, t->dD, evn, s, a, n, out, out_ld, col0);
   };
   if (which == 0 || which == 3)
     for (int e = 0; e < D.E; ++e) go((which == 3 ? D.E + 2 : 0) + e, D.E, e);
