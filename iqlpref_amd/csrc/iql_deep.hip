@@ -157,7 +157,7 @@ __device__ __forceinline__ void tile_mma2(const typename Prec<BF16>::T *arow, co
 template <bool BF16, class Hidden, class Final>
 __device__ __forceinline__ void deep_layers(const DeepDesc &D, const DeepEval &N, const DeepStep *A, bool dropout,
                                             int rowblk, typename Prec<BF16>::T *in, typename Prec<BF16>::T *out,
-                                            Hidden hidden, Final final) {
+                                            const DeepNet *TN, Hidden hidden, Final final) {
   using P = Prec<BF16>;
   using T = typename P::T;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4, ldw = D.lds_w, NL = D.NL;
@@ -167,6 +167,10 @@ __device__ __forceinline__ void deep_layers(const DeepDesc &D, const DeepEval &N
     const T *W = reinterpret_cast<const T *>(Lk.w);
     const float *bias = Lk.b;
     const bool last = l == NL - 1;
+    // (every descriptor field of this layer is read HERE, into registers: behind a global store the compiler
+    // must assume the descriptor changed and would fetch the field again -- a scalar-load round trip per tile)
+    T *const plane = (TN && !last) ? reinterpret_cast<T *>(TN->hT[l + 1]) : nullptr;
+    const bool tanh_out = N.tanh_out != 0;
     const T *arow = in + (size_t)r16 * ldw + q * P::EPV;
     for (int nt = 2 * wave; nt < ntile; nt += 2 * ((int)blockDim.x >> 6)) {
       const bool two = nt + 1 < ntile;  // (the output layer may have a single tile: its twin is computed and dropped)
@@ -196,9 +200,9 @@ __device__ __forceinline__ void deep_layers(const DeepDesc &D, const DeepEval &N
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) out[(size_t)(4 * q + i) * ldw + col] = P::from_f32(z[i]);
-          hidden(l, col, z);
+          hidden(plane, col, z);
         } else {
-          if (N.tanh_out) {
+          if (tanh_out) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) z[i] = P::round(tanhf(z[i]));
           }
@@ -260,9 +264,9 @@ __global__ __launch_bounds__(THREADS) void kd_forward(const DeepDesc *__restrict
   float *outs = D.outs;
   const int out_dim = N.out_dim, out_col = N.out_col;
   deep_layers<BF16>(
-      D, N, &A, N.dropout != 0, row0 / 4, bufA, bufB,
-      [&](int l, int col, const float a[4]) {
-        if (TN) put4T<BF16>(reinterpret_cast<T *>(TN->hT[l + 1]) + (size_t)col * BP + row0 + 4 * q, a);
+      D, N, &A, N.dropout != 0, row0 / 4, bufA, bufB, TN,
+      [&](T *plane, int col, const float a[4]) {
+        if (plane) put4T<BF16>(plane + (size_t)col * BP + row0 + 4 * q, a);
       },
       [&](int col, const float z[4]) {
         if (col < out_dim) stg16(outs + (size_t)(out_col + col) * BP + row0 + 4 * q, make_float4(z[0], z[1], z[2], z[3]));
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(256) void kd_infer(const DeepDesc *__restrict__ Dp,
   __syncthreads();
   const int out_dim = N.out_dim;
   deep_layers<BF16>(
-      D, N, nullptr, false, 0, bufA, bufB, [&](int, int, const float *) {},
+      D, N, nullptr, false, 0, bufA, bufB, nullptr, [&](T *, int, const float *) {},
       [&](int col, const float z[4]) {
         if (col < out_dim) {
 #pragma unroll
@@ -515,9 +519,19 @@ __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp
       P::mma(a, b, acc[t]);
     }
   }
+  // (descriptor fields the epilogue needs, read once into registers: behind its first global store the compiler
+  // must assume the descriptors changed and fetched D.params, N.has_target, ... again before EVERY access -- a
+  // chain of scalar-load round trips that was half of this launch)
   const float neg_step = A.coef.neg_step[N.group];
-  T *wc = reinterpret_cast<T *>(N.wc[l]), *wt = reinterpret_cast<T *>(N.wt[l]), *tc = reinterpret_cast<T *>(N.tc[l]);
-  const int64_t off_w = N.off_w[l], toff_w = N.toff_w[l];
+  T *const wc = reinterpret_cast<T *>(N.wc[l]), *const wt = reinterpret_cast<T *>(N.wt[l]), *const tc = reinterpret_cast<T *>(N.tc[l]);
+  const int64_t off_w = N.off_w[l], toff_w = N.toff_w[l], off_b = N.off_b[l], toff_b = N.toff_b[l];
+  float *const Pp = D.params, *const Pm = D.exp_avg, *const Pv = D.exp_avg_sq, *const Pt = D.target, *const Pg = D.grads;
+  const bool has_target = N.has_target != 0;
+  const struct {
+    float tau, one_m_tau;
+    int polyak_convex;
+  } PK = {D.tau, D.one_m_tau, D.polyak_convex};
+  const AdamCoef coef = A.coef;
   if (vec) {
     const int k0 = it.i0 + 16 * wave + 4 * q;  // (k0 + 3 < Kn whenever k0 < Kn: both are multiples of 4)
 #pragma unroll
@@ -525,27 +539,27 @@ __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp
       const int n = it.o0 + 16 * t + r16;
       if (n >= Nn || k0 >= Kn) continue;
       const int64_t o = off_w + (int64_t)n * Kn + k0, to = toff_w + (int64_t)n * Kn + k0;
-      const float4 pp = __builtin_bit_cast(float4, ldg16(D.params + o)), mm = __builtin_bit_cast(float4, ldg16(D.exp_avg + o));
-      const float4 vv = __builtin_bit_cast(float4, ldg16(D.exp_avg_sq + o));
+      const float4 pp = __builtin_bit_cast(float4, ldg16(Pp + o)), mm = __builtin_bit_cast(float4, ldg16(Pm + o));
+      const float4 vv = __builtin_bit_cast(float4, ldg16(Pv + o));
       float p[4] = {pp.x, pp.y, pp.z, pp.w}, m[4] = {mm.x, mm.y, mm.z, mm.w}, v[4] = {vv.x, vv.y, vv.z, vv.w};
       float tg[4] = {0.f, 0.f, 0.f, 0.f}, g[4];
-      if (N.has_target) {
-        const float4 tt = __builtin_bit_cast(float4, ldg16(D.target + to));
+      if (has_target) {
+        const float4 tt = __builtin_bit_cast(float4, ldg16(Pt + to));
         tg[0] = tt.x, tg[1] = tt.y, tg[2] = tt.z, tg[3] = tt.w;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         g[i] = P::round(acc[t][i]);  // parameter gradients are the bf16 results widened (autocast)
-        adam_apply<AF>(p[i], m[i], v[i], g[i], A.coef, neg_step);
-        if (N.has_target) tg[i] = polyak(D, tg[i], p[i]);
+        adam_apply<AF>(p[i], m[i], v[i], g[i], coef, neg_step);
+        if (has_target) tg[i] = polyak(PK, tg[i], p[i]);
       }
-      if (D.grads) stg16(D.grads + o, make_float4(g[0], g[1], g[2], g[3]));
-      stg16(D.params + o, make_float4(p[0], p[1], p[2], p[3]));
-      stg16(D.exp_avg + o, make_float4(m[0], m[1], m[2], m[3]));
-      stg16(D.exp_avg_sq + o, make_float4(v[0], v[1], v[2], v[3]));
+      if (Pg) stg16(Pg + o, make_float4(g[0], g[1], g[2], g[3]));
+      stg16(Pp + o, make_float4(p[0], p[1], p[2], p[3]));
+      stg16(Pm + o, make_float4(m[0], m[1], m[2], m[3]));
+      stg16(Pv + o, make_float4(v[0], v[1], v[2], v[3]));
       put4T<BF16>(wc + fidx<P>(n, k0, nkw), p);  // (4 consecutive, 4-aligned k of one row stay contiguous)
-      if (N.has_target) {
-        stg16(D.target + to, make_float4(tg[0], tg[1], tg[2], tg[3]));
+      if (has_target) {
+        stg16(Pt + to, make_float4(tg[0], tg[1], tg[2], tg[3]));
         put4T<BF16>(tc + fidx<P>(n, k0, nkw), tg);
       }
       if (wt) {
@@ -564,16 +578,16 @@ __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp
         if (n < Nn && k < Kn) {
           const float g = P::round(acc[t][i]);
           const int64_t o = off_w + (int64_t)n * Kn + k;
-          float p = ldg(D.params + o), m = ldg(D.exp_avg + o), v = ldg(D.exp_avg_sq + o);
-          if (D.grads) stg(D.grads + o, g);
-          adam_apply<AF>(p, m, v, g, A.coef, neg_step);
-          stg(D.params + o, p), stg(D.exp_avg + o, m), stg(D.exp_avg_sq + o, v);
+          float p = ldg(Pp + o), m = ldg(Pm + o), v = ldg(Pv + o);
+          if (Pg) stg(Pg + o, g);
+          adam_apply<AF>(p, m, v, g, coef, neg_step);
+          stg(Pp + o, p), stg(Pm + o, m), stg(Pv + o, v);
           stg(wc + fidx<P>(n, k, nkw), P::from_f32(p));
           if (wt) stg(wt + fidx<P>(k, n, nkt), P::from_f32(p));
-          if (N.has_target) {
+          if (has_target) {
             const int64_t to = toff_w + (int64_t)n * Kn + k;
-            const float tn = polyak(D, ldg(D.target + to), p);
-            stg(D.target + to, tn);
+            const float tn = polyak(PK, ldg(Pt + to), p);
+            stg(Pt + to, tn);
             stg(tc + fidx<P>(n, k, nkw), P::from_f32(tn));
           }
         }
@@ -587,14 +601,14 @@ __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp
       const float gs = P::round(xor32_sum(xor16_sum(bsum[t])));
       const int n = bias_q ? it.o0 + 16 * t + r16 : it.o0 + 16 * wave + r16;
       if (q == 0 && n < Nn) {
-        const int64_t o = N.off_b[l] + n;
-        float p = ldg(D.params + o), m = ldg(D.exp_avg + o), v = ldg(D.exp_avg_sq + o);
-        if (D.grads) stg(D.grads + o, gs);
-        adam_apply<AF>(p, m, v, gs, A.coef, neg_step);
-        stg(D.params + o, p), stg(D.exp_avg + o, m), stg(D.exp_avg_sq + o, v);
-        if (N.has_target) {
-          const int64_t to = N.toff_b[l] + n;
-          stg(D.target + to, polyak(D, ldg(D.target + to), p));
+        const int64_t o = off_b + n;
+        float p = ldg(Pp + o), m = ldg(Pm + o), v = ldg(Pv + o);
+        if (Pg) stg(Pg + o, gs);
+        adam_apply<AF>(p, m, v, gs, coef, neg_step);
+        stg(Pp + o, p), stg(Pm + o, m), stg(Pv + o, v);
+        if (has_target) {
+          const int64_t to = toff_b + n;
+          stg(Pt + to, polyak(PK, ldg(Pt + to), p));
         }
       }
     }
