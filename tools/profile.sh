@@ -15,8 +15,28 @@ mkdir -p $OUT
 # which library the set was collected on (bench.py labels every profile-derived figure with it)
 python -c "from iqlpref_amd import _lib; import json; print(json.dumps({'build': _lib.build_tag(), 'tag': '$TAG'}))" > $OUT/meta.json
 export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 3000 --warmup 300 $ARGS > $OUT/trace.json
-echo "trace done"
+# The tracer's pacing of graph replays is bimodal on this pool: the same library on one box traces at 57-59k or
+# at 42-45k steps/s (67k untraced), run by run (tools/ab_trace.sh, gpurun_out of round 4), and in the slow mode
+# every kernel measures 5-9 % longer (wider gaps between dispatches: colder caches and clocks).  The pass is
+# repeated up to three times and the LEAST perturbed run (highest traced rate) is kept; all rates go to meta.json.
+best=0; rates=""
+for try in 1 2 3; do
+  rm -rf $OUT/trace_try
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_try -- python bench.py --steps 3000 --warmup 300 $ARGS > $OUT/trace_try.json
+  rate=$(python -c "import json; print(int(json.loads(open('$OUT/trace_try.json').read().strip().splitlines()[-1])['value']))")
+  rates="$rates $rate"
+  if [ "$rate" -gt "$best" ]; then best=$rate; rm -rf $OUT/trace; mv $OUT/trace_try $OUT/trace; mv $OUT/trace_try.json $OUT/trace.json; fi
+  if [ "$rate" -gt 52000 ]; then break; fi
+done
+rm -rf $OUT/trace_try $OUT/trace_try.json
+python - <<PY
+import json
+m = json.load(open("$OUT/meta.json"))
+m["headline_trace_rates_steps_per_s"] = [int(x) for x in "$rates".split()]
+m["headline_trace_kept"] = $best
+json.dump(m, open("$OUT/meta.json", "w"))
+PY
+echo "trace done (traced rates:$rates; kept $best)"
 # counter passes: short regions only.  Under a serialising counter pass, a long region of back-to-back
 # hipGraph launches ends in HSA_STATUS_ERROR_INVALID_PACKET_FORMAT: the packet the queue dumps is one of
 # OUR kernel dispatches whose `setup` field (number of grid dimensions) reads 0 -- it was rewritten on its
