@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -455,7 +456,13 @@ __device__ __forceinline__ void deep_misc(const DeepDesc &D, const DeepStep &A) 
   }
 }
 
-template <bool BF16>
+// Columns of a tile: DEEP_TQ 16-wide groups of the Q operand per wave (the P operand gives every wave 16 rows).
+// Two instantiations: 64 x 16 tiles -- four times the work-groups, a quarter of the chain per lane: the launch
+// is a latency chain for one seed at batch 256 (update 13.1 -> 10.4 us at three hidden layers of 256 units,
+// 10.2 -> 5.4 us at one) -- and 64 x 64 tiles from batch 1024 on, where the operand panels (batch x 2 bytes per
+// row) are the traffic (E = 4 at batch 1024: 26.7 us against 32.3), and from 768 units on (H = 1024: 43.8 us
+// against 46.6).
+template <bool BF16, int DEEP_TQ>
 __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp, const DeepItem *__restrict__ items,
                                                  const DeepStep A) {
   using P = Prec<BF16>;
@@ -486,24 +493,24 @@ __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp
   const T *Pop = (vec ? Xp : Zp) + (size_t)16 * wave * BP, *Qop = vec ? Zp : Xp;
   // bias = sum of the deltas over the batch: from the dZ fragments, by the tiles of the first column block
   const bool bias_q = vec && it.i0 == 0 && wave == 0, bias_p = !vec && it.i0 == 0;  // (scalar)
-  f32x4 acc[4];
-  float bsum[4];
+  f32x4 acc[DEEP_TQ];
+  float bsum[DEEP_TQ];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}, bsum[t] = 0.f;
+  for (int t = 0; t < DEEP_TQ; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}, bsum[t] = 0.f;
   int ks = 0;
   for (; ks + 4 <= nk; ks += 4) {  // four k-steps (20 fragments) requested before the first MFMA
-    uint4 a[4], b[4][4];
+    uint4 a[4], b[4][DEEP_TQ];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       a[u] = ldg16(Pop + (size_t)(ks + u) * P::KM);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) b[u][t] = ldg16(Qop + (size_t)t * 16 * BP + (size_t)(ks + u) * P::KM);
+      for (int t = 0; t < DEEP_TQ; ++t) b[u][t] = ldg16(Qop + (size_t)t * 16 * BP + (size_t)(ks + u) * P::KM);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (bias_p) bsum[0] += frag_sum<BF16>(a[u]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < DEEP_TQ; ++t) {
         if (bias_q) bsum[t] += frag_sum<BF16>(b[u][t]);
         P::mma(a[u], b[u][t], acc[t]);
       }
@@ -513,7 +520,7 @@ __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp
     const uint4 a = ldg16(Pop + (size_t)ks * P::KM);
     if (bias_p) bsum[0] += frag_sum<BF16>(a);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < DEEP_TQ; ++t) {
       const uint4 b = ldg16(Qop + (size_t)t * 16 * BP + (size_t)ks * P::KM);
       if (bias_q) bsum[t] += frag_sum<BF16>(b);
       P::mma(a, b, acc[t]);
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp
   if (vec) {
     const int k0 = it.i0 + 16 * wave + 4 * q;  // (k0 + 3 < Kn whenever k0 < Kn: both are multiples of 4)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < DEEP_TQ; ++t) {
       const int n = it.o0 + 16 * t + r16;
       if (n >= Nn || k0 >= Kn) continue;
       const int64_t o = off_w + (int64_t)n * Kn + k0, to = toff_w + (int64_t)n * Kn + k0;
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp
   } else {
     const int n0 = it.o0 + 16 * wave + 4 * q;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < DEEP_TQ; ++t) {
       const int k = it.i0 + 16 * t + r16;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -596,7 +603,7 @@ __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp
   }
   if (bias_q || bias_p) {  // bf16(g.sum(0)) under autocast
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < DEEP_TQ; ++t) {
       if (bias_p && t > 0) break;
       const float gs = P::round(xor32_sum(xor16_sum(bsum[t])));
       const int n = bias_q ? it.o0 + 16 * t + r16 : it.o0 + 16 * wave + r16;
@@ -640,6 +647,7 @@ __global__ __launch_bounds__(256) void kd_sync(const DeepDesc *__restrict__ Dp) 
 // host side
 // ========================================================================
 struct DeepTrainer {
+  int tq = 4;  // kd_update's tile width in 16-column groups (1 or 4)
   DeepDesc D;
   DeepDesc *dD = nullptr;
   DeepItem *ditems = nullptr;
@@ -680,6 +688,8 @@ hipError_t deep_create(DeepTrainer **out, const iqlhip_trainer_config &cfg, int 
   D.next_off = round_up(S + A + 2, 4);
   D.opad = round_up(A, 16);
   D.nslab = B / 16;
+  t->tq = (D.BP >= 1024 || D.Hp >= 768) ? 4 : 1;  // (measured: tools/general_run.py with IQLHIP_GENERAL_TQ)
+  if (const char *e = getenv("IQLHIP_GENERAL_TQ")) t->tq = atoi(e) == 1 ? 1 : 4;  // (A/B knob)
   D.deterministic = cfg.deterministic, D.has_dropout = cfg.dropout_p > 0.f, D.polyak_convex = cfg.polyak_form == 1;
   D.two_over_B = 2.0f / (float)B, D.inv_E = 1.0f / (float)E;
   D.discount = cfg.discount, D.tau = cfg.tau, D.beta = cfg.beta, D.iql_tau = cfg.iql_tau;
@@ -733,8 +743,14 @@ hipError_t deep_create(DeepTrainer **out, const iqlhip_trainer_config &cfg, int 
   std::vector<DeepItem> items;
   for (int n = 0; n < NT; ++n)
     for (int l = 0; l < NL; ++l)
-      for (int o0 = 0; o0 < D.net[n].N[l]; o0 += 64)
-        for (int i0 = 0; i0 < D.net[n].K[l]; i0 += 64) items.push_back(DeepItem{n, l, o0, i0});
+    {
+      // (kd_update: in-features a multiple of 4 -> transposed tile, 64 in-features x 16 tq out-features;
+      // else 64 out-features x 16 tq in-features)
+      const bool vec = (D.net[n].K[l] & 3) == 0;
+      const int so = vec ? 16 * t->tq : 64, si = vec ? 64 : 16 * t->tq;
+      for (int o0 = 0; o0 < D.net[n].N[l]; o0 += so)
+        for (int i0 = 0; i0 < D.net[n].K[l]; i0 += si) items.push_back(DeepItem{n, l, o0, i0});
+    }
   items.push_back(DeepItem{-1, 0, 0, 0});
   t->n_items = (int)items.size();
   add(items.size() * sizeof(DeepItem));
@@ -853,10 +869,14 @@ hipError_t deep_step(DeepTrainer *t, const DeepStep &a, hipStream_t st, hipEvent
   else
     hipLaunchKernelGGL((kd_backward<false, 256>), gb, dim3(256), t->lds_bytes, st, t->dD, a);
   DEEP_EV(2);
-  if (t->bf16)
-    hipLaunchKernelGGL(kd_update<true>, gu, dim3(256), 0, st, t->dD, t->ditems, a);
+  if (t->bf16 && t->tq == 1)
+    hipLaunchKernelGGL((kd_update<true, 1>), gu, dim3(256), 0, st, t->dD, t->ditems, a);
+  else if (t->bf16)
+    hipLaunchKernelGGL((kd_update<true, 4>), gu, dim3(256), 0, st, t->dD, t->ditems, a);
+  else if (t->tq == 1)
+    hipLaunchKernelGGL((kd_update<false, 1>), gu, dim3(256), 0, st, t->dD, t->ditems, a);
   else
-    hipLaunchKernelGGL(kd_update<false>, gu, dim3(256), 0, st, t->dD, t->ditems, a);
+    hipLaunchKernelGGL((kd_update<false, 4>), gu, dim3(256), 0, st, t->dD, t->ditems, a);
   DEEP_EV(3);
 #undef DEEP_EV
   return hipGetLastError();
