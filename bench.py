@@ -563,7 +563,7 @@ def main():
                     "kernel_us_events": {"kd_forward": evg[0], "kd_backward": evg[1], "kd_update": evg[2]},
                     "roofline": roofline_block("kd_update (three hidden layers of 256 units)", byg.value - gath, evg[2],
                                                "plain launches; HIP events around each kernel",
-                                               f"{PROFILE_TAG}_general_kernel_stats.csv", ("kd_update<true>",),
+                                               f"{PROFILE_TAG}_general_kernel_stats.csv", ("kd_update<true",),
                                                "plain launches under rocprofv3 --kernel-trace", _lib.build_tag()),
                     "note": "the general layer-wise step on a shape the tuned three-kernel step does not take "
                             "(coverage path); not `value`"}
