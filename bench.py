@@ -109,7 +109,8 @@ def profile_kernel_avg(fname, *needles):
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             if all(n in row.get("Name", "") for n in needles):
-                return {"kernel": row["Name"].split("(")[0].replace("void iqlhip::", ""), "calls": int(row["Calls"]),
+                name = row["Name"].replace("(anonymous namespace)::", "")
+                return {"kernel": name.split("(")[0].replace("void iqlhip::", ""), "calls": int(row["Calls"]),
                         "kernel_avg_ns": float(row["AverageNs"])}
     return None
 
