@@ -39,11 +39,14 @@ static void lcg_fill(float *dst, int64_t n, uint32_t seed, float scale) {
   }
 }
 
-int main(void) {
-  enum { S = 11, A = 3, H = 64, B = 32, N = 500, STEPS = 12 };
+/* abi_smoke [n_hidden hidden_dim]: default 2 x 64 (the tuned step); any other depth / width runs on the general
+ * layer-wise step behind the same entry points */
+int main(int argc, char **argv) {
+  enum { S = 11, A = 3, B = 32, N = 500, STEPS = 12 };
+  const int NH = argc > 2 ? atoi(argv[1]) : 2, H = argc > 2 ? atoi(argv[2]) : 64, NL = NH + 1;
   iqlhip_trainer_config cfg;
   memset(&cfg, 0, sizeof(cfg));
-  cfg.state_dim = S, cfg.action_dim = A, cfg.hidden_dim = H, cfg.batch_size = B;
+  cfg.state_dim = S, cfg.action_dim = A, cfg.hidden_dim = H, cfg.batch_size = B, cfg.n_hidden = NH;
   cfg.deterministic = 0, cfg.precision = IQLHIP_PREC_FP32, cfg.dropout_p = -1.0f;
   cfg.discount = 0.99f, cfg.tau = 0.005f, cfg.beta = 3.0f, cfg.iql_tau = 0.7f;
   cfg.lr_q = cfg.lr_v = cfg.lr_actor = 3e-4;
@@ -56,10 +59,13 @@ int main(void) {
   float *hp = (float *)calloc((size_t)n_params, sizeof(float));
   /* tensor k gets its own stream of the recurrence (sizes from consecutive offsets) */
   const int in_dim[4] = {S + A, S + A, S, S}, out_dim[4] = {1, 1, 1, A};
-  for (int n = 0; n < 4; ++n) {
-    const int64_t sz[6] = {(int64_t)H * in_dim[n], H, (int64_t)H * H, H, (int64_t)out_dim[n] * H, out_dim[n]};
-    for (int k = 0; k < 6; ++k) lcg_fill(hp + off[n * 6 + k], sz[k], 1000u + (uint32_t)(n * 6 + k), 0.25f);
-  }
+  for (int n = 0; n < 4; ++n)
+    for (int l = 0; l < NL; ++l) { /* W_l [rows][cols], b_l [rows]: 2 NL offsets per network */
+      const int64_t rows = l == NL - 1 ? out_dim[n] : H, cols = l == 0 ? in_dim[n] : H;
+      const int k = (n * NL + l) * 2;
+      lcg_fill(hp + off[k], rows * cols, 1000u + (uint32_t)k, 0.25f);
+      lcg_fill(hp + off[k + 1], rows, 1000u + (uint32_t)k + 1u, 0.25f);
+    }
   /* log_std stays 0 (the reference's init) */
   iqlhip_arenas ar;
   memset(&ar, 0, sizeof(ar));
@@ -106,7 +112,9 @@ int main(void) {
   int64_t it = 0;
   double lr = 0;
   CHECK(iqlhip_trainer_get_step(t, &it, &lr));
-  printf("total_it %lld\n", (long long)it);
+  int32_t kind = -1;
+  CHECK(iqlhip_trainer_step_kind(t, &kind));
+  printf("total_it %lld step_kind %d\n", (long long)it, kind);
   for (int i = 0; i < STEPS; ++i) printf("%a %a %a\n", losses[3 * i], losses[3 * i + 1], losses[3 * i + 2]);
   CHECK(iqlhip_trainer_destroy(t));
   return 0;

@@ -24,7 +24,9 @@ def lcg_fill(n, seed, scale):
     return out
 
 
-def test_plain_c_program_matches_the_python_binding(tmp_path):
+@pytest.mark.parametrize("NH,H,kind", [(2, 64, 0), (3, 40, 1)])
+def test_plain_c_program_matches_the_python_binding(tmp_path, NH, H, kind):
+    """kind: 0 = the tuned step, 1 = the general layer-wise step (iqlhip_trainer_step_kind)."""
     import iqlpref_amd as ia
     cc = shutil.which("gcc") or shutil.which("cc")
     if cc is None or not os.path.isdir("/opt/rocm/include"):
@@ -35,19 +37,19 @@ def test_plain_c_program_matches_the_python_binding(tmp_path):
                     "-I", os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
                     "-L", libdir, "-l:libiqlhip.so", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
                     f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
-    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout.split("\n")
-    assert out[0] == "total_it 12"
+    out = subprocess.run([exe, str(NH), str(H)], check=True, capture_output=True, text=True, timeout=120).stdout.split("\n")
+    assert out[0] == f"total_it 12 step_kind {kind}"
     got_c = np.array([[float.fromhex(x) for x in line.split()] for line in out[1:13]], dtype=np.float32)
 
-    S, A, H, B, N, STEPS = 11, 3, 64, 32, 500, 12
-    q, v = ia.TwinQ(S, A, hidden_dim=H), ia.ValueFunction(S, hidden_dim=H)
-    actor = ia.GaussianPolicy(S, A, 1.0, hidden_dim=H)
+    S, A, B, N, STEPS = 11, 3, 32, 500, 12
+    q, v = ia.TwinQ(S, A, hidden_dim=H, n_hidden=NH), ia.ValueFunction(S, hidden_dim=H, n_hidden=NH)
+    actor = ia.GaussianPolicy(S, A, 1.0, hidden_dim=H, n_hidden=NH)
     mods = [q.q1, q.q2, v.v, actor.net]
     with torch.no_grad():
         for n, m in enumerate(mods):
             for li, lin in enumerate(m.linears()):
-                w = lcg_fill(lin.weight.numel(), 1000 + n * 6 + 2 * li, 0.25).reshape(lin.weight.shape)
-                b = lcg_fill(lin.bias.numel(), 1000 + n * 6 + 2 * li + 1, 0.25)
+                w = lcg_fill(lin.weight.numel(), 1000 + (n * (NH + 1) + li) * 2, 0.25).reshape(lin.weight.shape)
+                b = lcg_fill(lin.bias.numel(), 1000 + (n * (NH + 1) + li) * 2 + 1, 0.25)
                 lin.weight.copy_(torch.from_numpy(w))
                 lin.bias.copy_(torch.from_numpy(b))
     q, v, actor = q.to(DEV), v.to(DEV), actor.to(DEV)
