@@ -404,6 +404,8 @@ def test_shapes_beyond_the_goldens_vs_oracle(gh, S, A, H, B, det, drop, E, mode)
     (45, 24, 100, 3, 48, False, 0.1, 2),     # Philox dropout masks behind three hidden layers (streams 1, 2, 10)
     (29, 8, 80, 5, 1024, False, None, 4),    # E = 4 critics, batch 1024
     (17, 6, 24, 6, 16, True, 0.2, 3),        # the deepest, one 16-row slab
+    (100, 28, 48, 2, 32, False, None, 2),    # the widest input (S + A = 128)
+    (20, 32, 80, 2, 32, False, None, 2),     # the widest output (A = 32: two output tiles)
     (29, 8, 256, 2, 64, False, None, 2)])    # (IQLHIP_FORCE_GENERAL only: the default shape through the general step)
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_general_step_shapes_vs_oracle(gh, S, A, H, NH, B, det, drop, E, mode):
