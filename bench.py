@@ -568,6 +568,14 @@ def main():
                                                "plain launches under rocprofv3 --kernel-trace", _lib.build_tag()),
                     "note": "the general layer-wise step on a shape the tuned three-kernel step does not take "
                             "(coverage path); not `value`"}
+                tpg = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_general_traffic.json")
+                if os.path.exists(tpg):  # PMC bytes of a separate rocprofv3 run (tools/profile.sh)
+                    with open(tpg) as f:
+                        tjg = json.load(f)
+                    out["general_step"]["roofline"]["traffic"] = tjg.get("kd_update_bytes_per_launch")
+                    out["general_step"]["roofline"]["traffic_source"] = {
+                        "file": f"profiles/{PROFILE_TAG}_general_traffic.json", "build": tjg.get("build"),
+                        "matches_this_build": tjg.get("build") == _lib.build_tag()}
                 del trg
             except Exception as e:
                 out["general_step"] = {"error": f"{type(e).__name__}: {e}"}

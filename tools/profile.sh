@@ -76,7 +76,12 @@ echo "ens4 / pen done"
 # the general layer-wise step (three hidden layers of 256 units, batch 256): kernel trace + stats
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/gen -- python tools/general_run.py 256 3 256 2 3000 > $OUT/general.json
 find $OUT/gen -name "*kernel_stats.csv" -exec cp {} $OUT/general_kernel_stats.csv \;
-rm -rf $OUT/gen
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/genf -- python tools/general_run.py 256 3 256 2 300 > /dev/null
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/genw -- python tools/general_run.py 256 3 256 2 300 > /dev/null
+python tools/pmc_summary.py $OUT/genf 1 $OUT/general_pmc_fetch_size.json > /dev/null
+python tools/pmc_summary.py $OUT/genw 1 $OUT/general_pmc_write_size.json > /dev/null
+python tools/traffic_json.py $OUT/general_pmc_fetch_size.json $OUT/general_pmc_write_size.json $OUT/general_traffic.json
+rm -rf $OUT/gen $OUT/genf $OUT/genw
 echo "general done"
 python tools/pmc_summary.py $OUT/gfetch 1 $OUT/group8_pmc_fetch_size.json > /dev/null
 python tools/pmc_summary.py $OUT/gwrite 1 $OUT/group8_pmc_write_size.json > /dev/null
