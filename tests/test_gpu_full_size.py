@@ -151,3 +151,39 @@ def test_full_length_run_of_a_million_updates():
     assert 0 < last[:, 0].mean() < 1.0 and 0 < last[:, 1].mean() < 10.0
     assert not torch.equal(tr._target, tr._params[:tr._n_target])  # Polyak average, not a copy
     assert dt < 120, f"1M updates took {dt:.0f} s"
+
+
+def test_general_step_runs_a_full_schedule_to_the_end():
+    """The general layer-wise step (three hidden layers of 96 units with actor dropout: a shape the tuned step does not
+    take) through a whole cosine schedule of 50,000 updates: finite state, step counts, lr -> 0 at T_max, a critic
+    that fits (losses small and positive), a Polyak-averaged target."""
+    import iqlpref_amd as ia
+    S, A, N, T = 17, 6, 200_000, 50_000
+    rng = np.random.default_rng(1)
+    data = {"observations": rng.standard_normal((N, S), dtype=np.float32),
+            "actions": rng.uniform(-1, 1, (N, A)).astype(np.float32),
+            "rewards": rng.standard_normal(N).astype(np.float32) * 0.1,
+            "next_observations": rng.standard_normal((N, S), dtype=np.float32),
+            "terminals": (rng.uniform(size=N) < 1e-2).astype(np.float32)}
+    buf = ia.ReplayBuffer(S, A, N, DEV)
+    buf.load_d4rl_dataset(data)
+    torch.manual_seed(1)
+    kw = dict(hidden_dim=96, n_hidden=3)
+    q, v = ia.TwinQ(S, A, **kw).to(DEV), ia.ValueFunction(S, **kw).to(DEV)
+    actor = ia.GaussianPolicy(S, A, 1.0, dropout=0.1, **kw).to(DEV)
+    tr = ia.ImplicitQLearning(
+        max_action=1.0, actor=actor, actor_optimizer=torch.optim.Adam(actor.parameters(), lr=3e-4), q_network=q,
+        q_optimizer=torch.optim.Adam(q.parameters(), lr=3e-4), v_network=v,
+        v_optimizer=torch.optim.Adam(v.parameters(), lr=3e-4), iql_tau=0.7, beta=3.0, max_steps=T, device=DEV, seed=1)
+    assert tr.step_kind(256) == "general"
+    first = tr.train_steps(buf, 1_000, 256).cpu().numpy()
+    tr.train_steps(buf, T - 2_000, 256, return_losses=False)
+    last = tr.train_steps(buf, 1_000, 256).cpu().numpy()
+    assert tr.total_it == T and np.isfinite(first).all() and np.isfinite(last).all()
+    assert torch.isfinite(tr._params).all() and torch.isfinite(tr._exp_avg_sq).all() and torch.isfinite(tr._target).all()
+    assert abs(tr.actor_optimizer.param_groups[0]["lr"]) < 1e-18 and tr.actor_lr_schedule.last_epoch == T
+    sd = tr.state_dict()
+    assert sd["total_it"] == T and all(float(st["step"]) == T for st in sd["actor_optimizer"]["state"].values())
+    # the critic settles at the noise floor of its TD targets (rewards are N(0, 0.1^2): 0.01), below where it started
+    assert 0 < last[:, 1].mean() < first[:10, 1].mean() and last[:, 1].mean() < 0.02 and 0 < last[:, 0].mean() < 1.0
+    assert not torch.equal(tr._target, tr._params[:tr._n_target])
