@@ -461,7 +461,7 @@ __device__ __forceinline__ void deep_misc(const DeepDesc &D, const DeepStep &A) 
 // is a latency chain for one seed at batch 256 (update 13.1 -> 10.4 us at three hidden layers of 256 units,
 // 10.2 -> 5.4 us at one) -- and 64 x 64 tiles from batch 1024 on, where the operand panels (batch x 2 bytes per
 // row) are the traffic (E = 4 at batch 1024: 26.7 us against 32.3), and from 768 units on (H = 1024: 43.8 us
-// against 46.6).
+// against 46.6), provided such tiles still make ~150 work-groups (deep_create).
 template <bool BF16, int DEEP_TQ>
 __global__ __launch_bounds__(256) void kd_update(const DeepDesc *__restrict__ Dp, const DeepItem *__restrict__ items,
                                                  const DeepStep A) {
@@ -688,8 +688,7 @@ hipError_t deep_create(DeepTrainer **out, const iqlhip_trainer_config &cfg, int 
   D.next_off = round_up(S + A + 2, 4);
   D.opad = round_up(A, 16);
   D.nslab = B / 16;
-  t->tq = (D.BP >= 1024 || D.Hp >= 768) ? 4 : 1;  // (measured: tools/general_run.py with IQLHIP_GENERAL_TQ)
-  if (const char *e = getenv("IQLHIP_GENERAL_TQ")) t->tq = atoi(e) == 1 ? 1 : 4;  // (A/B knob)
+  const char *tq_env = getenv("IQLHIP_GENERAL_TQ");  // (A/B knob: 1 or 4; the rule sits with the item table below)
   D.deterministic = cfg.deterministic, D.has_dropout = cfg.dropout_p > 0.f, D.polyak_convex = cfg.polyak_form == 1;
   D.two_over_B = 2.0f / (float)B, D.inv_E = 1.0f / (float)E;
   D.discount = cfg.discount, D.tau = cfg.tau, D.beta = cfg.beta, D.iql_tau = cfg.iql_tau;
@@ -739,7 +738,17 @@ hipError_t deep_create(DeepTrainer **out, const iqlhip_trainer_config &cfg, int 
   add((size_t)D.OUTW * D.BP * 4);
   add((size_t)NT * D.nslab * 4), add((size_t)D.nslab * A * 4);
   add(sizeof(DeepDesc));
-  // update items
+  // update items.  Tile width (kd_update<.., TQ>): 64 x 64 tiles where the operand panels are the traffic (batch
+  // >= 1024) or the matrices are large (width >= 768) AND such tiles still make ~150 work-groups; 64 x 16 otherwise
+  // (measured with IQLHIP_GENERAL_TQ, tools/general_run.py: E = 4 / batch 1024 with three hidden layers, 216 wide
+  // tiles: 26.4 us against 32.1; with two, 144: 25.7 against 18.6; width 1024: 43.9 against 46.5)
+  {
+    int wide = 0;
+    for (int n = 0; n < NT; ++n)
+      for (int l = 0; l < NL; ++l) wide += ((D.net[n].N[l] + 63) / 64) * ((D.net[n].K[l] + 63) / 64);
+    t->tq = ((D.BP >= 1024 || D.Hp >= 768) && wide >= 150) ? 4 : 1;
+    if (tq_env) t->tq = atoi(tq_env) == 1 ? 1 : 4;
+  }
   std::vector<DeepItem> items;
   for (int n = 0; n < NT; ++n)
     for (int l = 0; l < NL; ++l)
